@@ -1,0 +1,160 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference) on CPU.
+
+Build-container only (the reference never travels to the GPU box).  Nothing of the reference is
+copied: this script imports it, feeds it weights/batches produced by oracle/volta_ref.py's
+deterministic generators and stores inputs + expected outputs.
+
+Harness-side shims (no reference file is modified):
+  * empty stub modules for boto3 / botocore / requests-free import of volta/utils.py:20-22
+  * Tensor.cuda -> identity, because volta/embeddings.py:383 hard-codes .cuda()
+
+Usage:  python oracle/make_golden.py            (writes every fixture)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+
+from oracle import volta_ref as R  # noqa: E402
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    for name in ("boto3", "botocore", "botocore.exceptions"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["botocore.exceptions"].ClientError = type("ClientError", (Exception,), {})
+    sys.modules["botocore"].exceptions = sys.modules["botocore.exceptions"]
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    sys.path.insert(0, REF)
+    from volta.config import BertConfig
+    from volta.encoders import BertForVLPreTraining
+    return BertConfig, BertForVLPreTraining
+
+
+TINY_BASE = dict(
+    vocab_size=200, hidden_size=64, num_attention_heads=4, intermediate_size=128, pooler_size=48,
+    max_position_embeddings=64, type_vocab_size=2, num_locs=5, add_global_imgfeat="first",
+    v_feature_size=32, v_hidden_size=64, v_num_attention_heads=4, v_intermediate_size=128, v_pooler_size=48,
+    visual_target_weights={"0": 1.0}, fusion_method="mul", v_initializer_range=0.02,
+)
+
+
+def tiny_configs():
+    c = {}
+    c["tiny_vilbert"] = dict(TINY_BASE, image_embeddings="vilbert",
+                             tt_attn_sublayers=[0, 2, 6], tv_attn_sublayers=[4], vt_attn_sublayers=[4], vv_attn_sublayers=[6],
+                             t_ff_sublayers=[1, 3, 5, 7], v_ff_sublayers=[5, 7])
+    c["tiny_lxmert"] = dict(TINY_BASE, image_embeddings="lxmert",
+                            tt_attn_sublayers=[0, 2, 5], vv_attn_sublayers=[0, 5], tv_attn_sublayers=[4], vt_attn_sublayers=[4],
+                            shared_sublayers=[4], t_ff_sublayers=[1, 3, 6], v_ff_sublayers=[1, 6])
+    single = dict(tt_attn_sublayers=[0, 2], tv_attn_sublayers=[0, 2], vt_attn_sublayers=[0, 2], vv_attn_sublayers=[0, 2],
+                  t_ff_sublayers=[1, 3], v_ff_sublayers=[1, 3], shared_sublayers=[0, 1, 2, 3], single_ln_sublayers=[0, 1, 2, 3])
+    c["tiny_uniter"] = dict(TINY_BASE, image_embeddings="uniter", **single)
+    c["tiny_visualbert"] = dict(TINY_BASE, image_embeddings="visualbert", **single)
+    c["tiny_vlbert"] = dict(TINY_BASE, image_embeddings="vl-bert", type_vocab_size=3, image_head_ln=False,
+                            v_coordinate_embeddings_dim=4, **single)
+    # gated general case: text attends to text AND vision with UNSHARED weights (joint softmax over two key sets)
+    c["tiny_gated"] = dict(TINY_BASE, image_embeddings="vilbert",
+                           tt_attn_sublayers=[0], tv_attn_sublayers=[0], vt_attn_sublayers=[0], vv_attn_sublayers=[0],
+                           t_ff_sublayers=[1], v_ff_sublayers=[1])
+    return c
+
+
+GRAD_KEYS = ["bert.embeddings.word_embeddings.weight", "bert.encoder.layer.0.attention_self.query.weight",
+             "bert.encoder.layer.0.attention_output.LayerNorm.weight", "bert.encoder.layer.1.output.dense.bias",
+             "cls.predictions.transform.dense.weight", "cls.imagePredictions.decoder_dict.0.weight",
+             "bert.t_pooler.dense.weight", "cls.bi_seq_relationship.weight"]
+
+
+def run_reference(BertConfig, Model, cfg_dict, sd, batch, want_grads=True):
+    cfg = BertConfig.from_dict(cfg_dict)
+    model = Model(cfg)
+    missing = model.load_state_dict(sd, strict=True)
+    model.eval()
+    b = {k: v.clone() for k, v in batch.items()}
+    lm, img, nsp = model(b["input_ids"], b["image_feat"], b["image_loc"], b["segment_ids"], b["input_mask"],
+                         b["image_mask"], b["lm_label_ids"], b["image_label"], b["image_cls"], None, None, None,
+                         None, None, b["is_match"])
+    seq_t, seq_v, pt, pv, _ = model.bert(b["input_ids"], batch["image_feat"].clone(), b["image_loc"], b["segment_ids"],
+                                         b["input_mask"], b["image_mask"])
+    out = dict(loss_lm=lm.detach().numpy(), loss_img=img.detach().numpy(), loss_nsp=nsp.detach().numpy(),
+               seq_t=seq_t.detach().numpy(), seq_v=seq_v.detach().numpy(),
+               pooled_t=pt.detach().numpy(), pooled_v=pv.detach().numpy())
+    if want_grads:
+        (lm + img + nsp).sum().backward()
+        named = dict(model.named_parameters())
+        for k in GRAD_KEYS:
+            if k in named and named[k].grad is not None:
+                out["grad::" + k] = named[k].grad.numpy().copy()
+        total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
+        out["grad_norm"] = np.array([float(total)])
+    return out, model
+
+
+def write_tiny(BertConfig, Model):
+    for name, cd in tiny_configs().items():
+        cfg = R.RefConfig(cd)
+        sd = R.make_weights(cfg, seed=7)
+        batch = R.synthetic_batch(cfg, B=3, T=6, R=4, seed=11, pad=True)
+        out, model = run_reference(BertConfig, Model, cd, sd, batch)
+        # the reference's own key order / shapes pin param_shapes()
+        ref_keys = list(model.state_dict().keys())
+        blob = {"cfg_json": np.array(__import__("json").dumps(cd)), "ref_keys": np.array(ref_keys)}
+        blob.update({"in::" + k: v.numpy() for k, v in batch.items()})
+        blob.update({"w::" + k: v.numpy() for k, v in sd.items()})
+        blob.update({"out::" + k: v for k, v in out.items()})
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(name, "losses", out["loss_lm"], out["loss_img"], out["loss_nsp"], os.path.getsize(path) // 1024, "KB")
+
+
+def write_ctrl(BertConfig, Model):
+    """The five real ctrl_* configs at B=2 (T=20, R=36 / 100 for vl-bert): weights come from the seed
+    generator (not stored), so only losses, pooled vectors, a hidden-state slice and checksums are."""
+    import json
+    for name in ("ctrl_vilbert_base", "ctrl_lxmert", "ctrl_uniter_base", "ctrl_visualbert_base", "ctrl_vl-bert_base"):
+        cd = json.load(open(os.path.join(ROOT, "config", name + ".json")))
+        cfg = R.RefConfig(cd)
+        sd = R.make_weights(cfg, seed=3, std=0.03)
+        Rn = 100 if "vl-bert" in name else 36
+        batch = R.synthetic_batch(cfg, B=2, T=20, R=Rn, seed=7)
+        out, model = run_reference(BertConfig, Model, cd, sd, batch, want_grads=True)
+        n_params = sum(p.numel() for p in model.parameters())
+        blob = {"n_params": np.array([n_params]), "n_keys": np.array([len(model.state_dict())]),
+                "ref_keys": np.array(list(model.state_dict().keys()))}
+        for k in ("loss_lm", "loss_img", "loss_nsp", "pooled_t", "pooled_v", "grad_norm"):
+            blob["out::" + k] = out[k]
+        blob["out::seq_t_slice"] = out["seq_t"][:, :, :64]
+        blob["out::seq_v_slice"] = out["seq_v"][:, :8, :64]
+        blob["out::seq_t_sum"] = np.array([out["seq_t"].astype(np.float64).sum()])
+        blob["out::seq_v_sum"] = np.array([out["seq_v"].astype(np.float64).sum()])
+        for k in GRAD_KEYS[1:]:
+            if "grad::" + k in out:
+                g = out["grad::" + k]
+                blob["out::gradslice::" + k] = g.reshape(g.shape[0], -1)[:16, :64] if g.ndim > 1 else g[:64]
+                blob["out::gradnorm::" + k] = np.array([np.sqrt((g.astype(np.float64) ** 2).sum())])
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(name, n_params, "losses", out["loss_lm"], out["loss_img"], out["loss_nsp"], os.path.getsize(path) // 1024, "KB")
+        del model, sd
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    BertConfig, Model = import_reference()
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if which in ("all", "tiny"):
+        write_tiny(BertConfig, Model)
+    if which in ("all", "ctrl"):
+        write_ctrl(BertConfig, Model)

@@ -1,0 +1,85 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) kernels of libvolta_hip.so.
+// wave = 64 lanes everywhere; bf16 is carried as raw uint16 bits.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vk {
+
+typedef uint16_t bf16_t;
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // one 16x16x32 / 32x32x16 MFMA A/B fragment
+typedef __attribute__((ext_vector_type(4))) short bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // one 16x16 accumulator fragment
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+
+#define VK_LDS __attribute__((address_space(3)))
+
+__device__ __forceinline__ float bf2f(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f) { return __builtin_bit_cast(uint16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// ---- wave reductions (64 lanes) -------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// ---- Philox-4x32-10: the engine's dropout stream ----------------------------------------------
+// Contract (mirrored by oracle/volta_ref.py:philox_u32): a dropout site sees its tensor as
+// [rows, C]; element (row, c) takes word (c & 3) of philox(counter = (c >> 2, row, site, 0),
+// key = (seed_lo, seed_hi)); it is KEPT iff word >= floor(p * 2^32) and scaled by 1/(1-p).
+__device__ __forceinline__ u32x4 philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    u32x4 r = {c0, c1, c2, c3};
+    return r;
+}
+
+struct DropCfg {              // by-value kernel argument
+    const uint64_t* seed;     // device word, bumped once per step by vk_step_begin (graph-replay safe)
+    uint32_t site;            // dropout site id (position in the reference's forward order)
+    uint32_t thr;             // floor(p * 2^32); 0 => dropout off
+    float scale;              // 1/(1-p)
+};
+
+__device__ __forceinline__ u32x4 drop_words(const DropCfg& d, uint64_t seed, uint32_t row, uint32_t c4) {
+    return philox4(c4, row, d.site, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+// ---- buffer resources (bounds-checked loads: out-of-range reads return 0) ---------------------
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
+
+// erf-GELU and its derivative (volta/encoders.py:130-136)
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    return cdf + x * 0.39894228040143268f * __expf(-0.5f * x * x);
+}
+
+// ds_read_b64_tr_b16: within each group of 16 lanes, lane 4q+p supplies the address of row q,
+// elements 4p..4p+3 of a 4x16 block of 16-bit values; lane i receives column i (rows 0..3).
+__device__ __forceinline__ bf16x4 lds_read_tr16(uint32_t byte_addr) {
+    bf16x4 r;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(byte_addr) : "memory");
+    return r;
+}
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+}  // namespace vk
