@@ -1,0 +1,143 @@
+"""GEMM kernels (vk_gemm_grouped) against fp32 matmuls of the same bf16 operands.  GPU only."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _mods():
+    from volta_amd import _lib as L, ops
+    return L, ops
+
+
+def rnd(shape, g, scale=1.0):
+    return (torch.randn(shape, generator=g, device="cuda") * scale).to(torch.bfloat16)
+
+
+def ref_mm(layout, A, B, L):
+    a, b = A.float(), B.float()
+    if layout == L.NT:
+        return a @ b.t()
+    if layout == L.NN:
+        return a @ b
+    return a.t() @ b
+
+
+SHAPES = [(128, 128, 64), (256, 384, 128), (300, 200, 192), (1000, 768, 768), (77, 1601, 256), (5120, 2304, 768), (64, 8, 1024)]
+
+
+@pytest.mark.parametrize("layout_name", ["NT", "NN", "TN"])
+@pytest.mark.parametrize("M,N,K", SHAPES)
+def test_gemm_f32_out(layout_name, M, N, K):
+    L, ops = _mods()
+    layout = getattr(L, layout_name)
+    g = torch.Generator(device="cuda").manual_seed(M * 7 + N * 3 + K)
+    if layout == L.TN:
+        K = K + 37          # contraction over rows: any count is legal, zero-filled by the bounds check
+    Np = (N + 7) // 8 * 8   # row-major operands with N columns need an 8-element aligned leading dim
+    Mp = (M + 7) // 8 * 8
+    if layout == L.NT:
+        A, B = rnd((M, K), g), rnd((N, K), g)
+        Av, Bv = A, B
+    elif layout == L.NN:
+        A = rnd((M, K), g)
+        B = torch.zeros(K, Np, device="cuda", dtype=torch.bfloat16)
+        B[:, :N] = rnd((K, N), g)
+        Av, Bv = A, B[:, :N]
+    else:
+        A = torch.zeros(K, Mp, device="cuda", dtype=torch.bfloat16)
+        A[:, :M] = rnd((K, M), g)
+        B = torch.zeros(K, Np, device="cuda", dtype=torch.bfloat16)
+        B[:, :N] = rnd((K, N), g)
+        Av, Bv = A[:, :M], B[:, :N]
+    ld = (N + 63) // 64 * 64
+    Cbuf = torch.full((M, ld), float("nan"), device="cuda")
+    bias = torch.randn(N, generator=g, device="cuda")
+    p = ops.gemm_problem(A, B, Cbuf, layout, M, N, K, bias=bias, n_store=ld)
+    ops.gemm_grouped(layout, L.EPI_F32, [p])
+    torch.cuda.synchronize()
+    ref = ref_mm(layout, Av, Bv, L) + bias
+    err = (Cbuf[:, :N] - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2e-3 * max(scale, 1.0), (err, scale)
+    assert torch.all(Cbuf[:, N:] == 0), "pad columns must be written as zeros"
+
+
+@pytest.mark.parametrize("epi", ["BF16", "GELU", "MULR", "ADDR", "RELU"])
+def test_gemm_epilogues(epi):
+    L, ops = _mods()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, N, K = 333, 3072, 768
+    A, B = rnd((M, K), g, 0.5), rnd((N, K), g, 0.05)
+    bias = torch.randn(N, generator=g, device="cuda") * 0.1
+    R = rnd((M, N), g)
+    Cb = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    C2 = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+    e = getattr(L, "EPI_" + epi)
+    p = ops.gemm_problem(A, B, Cb, L.NT, M, N, K, bias=None if epi == "MULR" else bias, R=R if epi in ("MULR", "ADDR") else None,
+                         C2=C2 if epi == "GELU" else None)
+    ops.gemm_grouped(L.NT, e, [p])
+    torch.cuda.synchronize()
+    u = A.float() @ B.float().t()
+    if epi == "BF16":
+        ref = u + bias
+    elif epi == "GELU":
+        x = (u + bias).double()
+        ref = torch.nn.functional.gelu(x).float()
+        x.requires_grad_(True)
+        torch.nn.functional.gelu(x).sum().backward()
+        assert (C2.float() - x.grad.float()).abs().max().item() < 1e-2
+    elif epi == "MULR":
+        ref = u * R.float()
+    elif epi == "ADDR":
+        ref = u + bias + R.float()
+    else:
+        ref = torch.relu(u + bias)
+    err = (Cb.float() - ref).abs()
+    assert (err <= 1e-2 * ref.abs() + 2e-2).all(), err.max().item()
+
+
+def test_gemm_grouped_dynamic_rows_and_bias_grad():
+    L, ops = _mods()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    # two forward problems in one launch, the second with a device-side row count
+    A1, B1 = rnd((512, 768), g), rnd((768, 768), g, 0.05)
+    A2, B2 = rnd((700, 768), g), rnd((768, 768), g, 0.05)
+    C1 = torch.zeros(512, 768, device="cuda", dtype=torch.bfloat16)
+    C2 = torch.full((700, 768), 7.0, device="cuda", dtype=torch.bfloat16)
+    n_dev = torch.tensor([130], device="cuda", dtype=torch.int32)
+    ops.gemm_grouped(L.NT, L.EPI_BF16, [ops.gemm_problem(A1, B1, C1, L.NT, 512, 768, 768),
+                                        ops.gemm_problem(A2, B2, C2, L.NT, 700, 768, 768, dyn=n_dev)])
+    torch.cuda.synchronize()
+    r1 = A1.float() @ B1.float().t()
+    r2 = A2.float() @ B2.float().t()
+    assert (C1.float() - r1).abs().max().item() < 0.05 * r1.abs().max().item()
+    assert (C2[:130].float() - r2[:130]).abs().max().item() < 0.05 * r2.abs().max().item()
+    assert torch.all(C2[130:] == 7.0), "rows beyond the device count must stay untouched"
+    # wgrad with fused bias gradient and a device-side contraction length
+    dY, X = rnd((900, 768), g), rnd((900, 3072), g)
+    dW = torch.zeros(768, 3072, device="cuda")
+    db = torch.zeros(768, device="cuda")
+    k_dev = torch.tensor([555], device="cuda", dtype=torch.int32)
+    ops.gemm_grouped(L.TN, L.EPI_F32, [ops.gemm_problem(dY, X, dW, L.TN, 768, 3072, 900, bias_grad=db, dyn=k_dev)])
+    torch.cuda.synchronize()
+    ref = dY[:555].float().t() @ X[:555].float()
+    assert (dW - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+    assert (db - dY[:555].float().sum(0)).abs().max().item() < 1e-2
+
+
+def test_gemm_strided_views():
+    """Q/K/V slices of a fused [M, 3H] buffer as A operand (lda = 3H) and as C (ldc = 3H)."""
+    L, ops = _mods()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    M, H = 200, 768
+    qkv = rnd((M, 3 * H), g)
+    W = rnd((H, H), g, 0.05)
+    out = torch.zeros(M, 3 * H, device="cuda", dtype=torch.bfloat16)
+    A = qkv[:, H:2 * H]
+    Cv = out[:, 2 * H:]
+    ops.gemm_grouped(L.NT, L.EPI_BF16, [ops.gemm_problem(A, W, Cv, L.NT, M, H, H)])
+    torch.cuda.synchronize()
+    ref = A.float() @ W.float().t()
+    assert (Cv.float() - ref).abs().max().item() < 0.05 * ref.abs().max().item()
+    assert torch.all(out[:, :2 * H] == 0)

@@ -1,0 +1,55 @@
+"""Fused dropout + residual + LayerNorm kernels against the oracle's layer_norm + autograd.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,H", [(37, 768), (1000, 768), (130, 1024), (9, 64)])
+@pytest.mark.parametrize("mode", ["eval", "pre", "post"])
+def test_ln_fwd_bwd(M, H, mode):
+    from volta_amd import _lib as L, ops
+    from oracle import volta_ref as R
+    g = torch.Generator().manual_seed(M + H)
+    d = torch.randn(M, H, generator=g).bfloat16()
+    x = torch.randn(M, H, generator=g).bfloat16()
+    gamma = 1 + 0.1 * torch.randn(H, generator=g)
+    beta = 0.1 * torch.randn(H, generator=g)
+    dy = torch.randn(M, H, generator=g).bfloat16()
+    p, seed, site, split = 0.1, 0x1234ABCD5678, 11, (M * 2) // 3
+    dev = "cuda"
+    seed_t = torch.zeros(1, dtype=torch.int64, device=dev)
+    ops.set_seed(seed_t, seed)
+    drop = L.dropout_cfg(seed_t.data_ptr(), site, 0.0 if mode == "eval" else p)
+    post = 1 if mode == "post" else 0
+    out_scale = 0.5 if mode == "post" else 1.0
+    dd_, xd, yd, zd = d.to(dev), x.to(dev), torch.empty(M, H, device=dev, dtype=torch.bfloat16), torch.empty(M, H, device=dev, dtype=torch.bfloat16)
+    mean, rstd = torch.empty(M, device=dev), torch.empty(M, device=dev)
+    ops.ln_fwd(dd_, xd, gamma.to(dev), beta.to(dev), yd, zd, mean, rstd, M, H, drop=drop, split_row=split, post=post, out_scale=out_scale)
+    # oracle with the replayed Philox masks
+    df, xf = d.float().requires_grad_(True), x.float().requires_grad_(True)
+    gm, bt = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    keep = torch.ones(M, H)
+    if mode != "eval":
+        keep = torch.cat([R.philox_keep_mask(seed, site, (split, H), p), R.philox_keep_mask(seed, site + 1, (M - split, H), p)]).float() / (1 - p)
+    if post:
+        zf = df + xf
+        yf = R.layer_norm(zf, gm, bt) * keep * out_scale
+    else:
+        zf = df * keep + xf
+        yf = R.layer_norm(zf, gm, bt) * out_scale
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(yd.float().cpu().numpy(), yf.detach().numpy(), atol=3e-2, rtol=1e-2)
+    np.testing.assert_allclose(mean.cpu().numpy(), zf.mean(-1).detach().numpy(), atol=1e-5)
+    yf.backward(dy.float())
+    partial = torch.empty(L.lib.vk_ln_bwd_partial_rows(M) * 2 * H, device=dev)
+    dz, ddd = torch.empty_like(yd), torch.empty_like(yd)
+    dgam, dbet = torch.empty(H, device=dev), torch.empty(H, device=dev)
+    ops.ln_bwd(dy.to(dev), zd, mean, rstd, gamma.to(dev), dz, ddd, partial, dgam, dbet, M, H, drop=drop, split_row=split, post=post, out_scale=out_scale)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dz.float().cpu().numpy(), xf.grad.numpy(), atol=3e-2, rtol=2e-2)
+    np.testing.assert_allclose(ddd.float().cpu().numpy(), df.grad.numpy(), atol=3e-2, rtol=2e-2)
+    tol = 2e-2 * max(1.0, float(gm.grad.abs().max()))
+    np.testing.assert_allclose(dgam.cpu().numpy(), gm.grad.numpy(), atol=tol)
+    np.testing.assert_allclose(dbet.cpu().numpy(), bt.grad.numpy(), atol=tol)

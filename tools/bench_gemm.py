@@ -1,0 +1,46 @@
+"""Micro-benchmark of vk_gemm_grouped on the GEMM shapes of one ctrl_vilbert_base step (B=256)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from volta_amd import _lib as L, ops
+
+
+def bench(name, layout, epi, M, N, K, iters=20):
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rnd = lambda *s: (torch.randn(*s, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    if layout == L.NT:
+        A, B = rnd(M, K), rnd(N, K)
+    elif layout == L.NN:
+        A, B = rnd(M, K), rnd(K, N)
+    else:
+        A, B = rnd(K, M), rnd(K, N)
+    Cb = torch.empty(M, N, device="cuda", dtype=torch.float32 if epi == L.EPI_F32 else torch.bfloat16)
+    C2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16) if epi == L.EPI_GELU else None
+    bias = torch.zeros(N, device="cuda")
+    p = ops.gemm_problem(A, B, Cb, layout, M, N, K, bias=bias, C2=C2)
+    for _ in range(3):
+        ops.gemm_grouped(layout, epi, [p])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        ops.gemm_grouped(layout, epi, [p])
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print("%-28s M=%5d N=%5d K=%5d  %8.1f us  %7.1f TF/s" % (name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9), flush=True)
+
+
+if __name__ == "__main__":
+    for Mrows, tag in ((5120, "text"), (9472, "vis")):
+        bench(tag + " qkv fwd NT", L.NT, L.EPI_BF16, Mrows, 2304, 768)
+        bench(tag + " out fwd NT", L.NT, L.EPI_BF16, Mrows, 768, 768)
+        bench(tag + " ffn-up fwd NT gelu", L.NT, L.EPI_GELU, Mrows, 3072, 768)
+        bench(tag + " ffn-down fwd NT", L.NT, L.EPI_BF16, Mrows, 768, 3072)
+        bench(tag + " ffn-up dgrad NN", L.NN, L.EPI_BF16, Mrows, 768, 3072)
+        bench(tag + " ffn-down dgrad NN", L.NN, L.EPI_BF16, Mrows, 3072, 768)
+        bench(tag + " ffn wgrad TN", L.TN, L.EPI_F32, 3072, 768, Mrows)
+        bench(tag + " out wgrad TN", L.TN, L.EPI_F32, 768, 768, Mrows)
+    bench("img-emb NT", L.NT, L.EPI_BF16, 9472, 768, 2048)
+    bench("square 4096", L.NT, L.EPI_BF16, 4096, 4096, 4096)
+    bench("square 8192", L.NT, L.EPI_BF16, 8192, 8192, 8192, iters=5)

@@ -1,0 +1,457 @@
+// Gated bimodal attention for gfx950, forward and backward: ONE launch per attention sub-layer covers
+// every present block of volta's BertGatedSelfAttention (tt, tv, vt, vv; volta/encoders.py:228-358):
+//   scores = Q K^T / sqrt(dh) + mask ; joint softmax of a query row over [text keys | vision keys] that
+//   its modality attends (encoders.py:285-314) ; per-block dropout ; context = P V summed over blocks.
+// One workgroup per (batch element, head).  K/V (and Q/dO in backward) of both modalities are staged
+// once into LDS in a "dual-use" image that serves ds_read_b128 row fragments and ds_read_b64_tr_b16
+// transposed fragments (cdna guide T10).  Every 16-query tile (forward, dQ) / 16-key tile (dK, dV) is
+// one wave's task.  MFMAs are issued in the swapped orientation (D = K Q^T) so that a lane owns one
+// query and the accumulator tile is directly the next MFMA's B operand (no LDS round trip for P).
+// Scores never touch HBM; the backward recomputes P from the saved log-sum-exp.
+// dh is fixed at 64 (every ctrl_* config); sequence lengths up to 64 text / 128 vision tokens.
+#include "common.h"
+#include "../../include/volta_hip.h"
+#include "util.h"
+
+namespace vk {
+
+constexpr int DH = 64;
+
+// dual-use LDS image of a [rows][64] bf16 tile: 128-B rows, 32-B blocks XOR-swizzled by (row>>1)&3
+__device__ __forceinline__ uint32_t img_off(int row, int col) {
+    return (uint32_t)(row * 128 + ((((col >> 4) ^ ((row >> 1) & 3)) << 5) | ((col & 15) << 1)));
+}
+// 8 consecutive dims [c8, c8+8) of one row: MFMA fragment for rows = (lane&15), k = dims
+__device__ __forceinline__ bf16x8 img_row_frag(uint32_t img, int row0, int ks, int lane) {
+    const int row = row0 + (lane & 15);
+    return *(const bf16x8 VK_LDS*)(uintptr_t)(img + img_off(row, ks * 32 + (lane >> 4) * 8));
+}
+// transposed fragment: output rows = the 16 dims [d0, d0+16), k = 32 tile rows in "pair order":
+// slot j<4 of lane group g is row rbase + 4g + j, slot j>=4 is row rbase + 16 + 4g + (j-4).
+__device__ __forceinline__ bf16x8 img_tr_frag(uint32_t img, int rbase, int d0, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int r0 = rbase + 4 * g + q, r1 = r0 + 16;
+    bf16x4 lo = lds_read_tr16(img + img_off(r0, d0 + 4 * p));
+    bf16x4 hi = lds_read_tr16(img + img_off(r1, d0 + 4 * p));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+// cooperative staging of rows [0, L) x 64 dims of one head into an image of RP rows (zero padded)
+__device__ __forceinline__ void stage_img(uint32_t img, const uint16_t* base, int ld, int L, int RP, int tid, int nthr) {
+    for (int idx = tid; idx < RP * 8; idx += nthr) {
+        const int row = idx >> 3, ch = idx & 7;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (row < L) v = *(const u32x4*)(base + (size_t)row * ld + ch * 8);
+        *(u32x4 VK_LDS*)(uintptr_t)(img + img_off(row, ch * 8)) = v;
+    }
+}
+
+__device__ __forceinline__ float group_max(float v) {   // over the 4 lanes sharing lane&15
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
+}
+__device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
+    bf16x8 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { r[i] = (short)f2bf(a[i]); r[4 + i] = (short)f2bf(b[i]); }
+    return r;
+}
+
+struct AttnK {                       // kernel-side copy of vk_attn_args (+ backward pointers)
+    const uint16_t* q[2]; const uint16_t* k[2]; const uint16_t* v[2];
+    int32_t ld[2], L[2];
+    const float* mask[2];
+    uint16_t* ctx[2]; int32_t ldo[2];
+    float* lse[2];
+    int32_t B, nh;
+    int32_t gate[2][2];
+    vk_dropout drop[2][2];
+    float scale;
+    // backward only
+    const uint16_t* dctx[2];
+    uint16_t* dq[2]; uint16_t* dk[2]; uint16_t* dv[2];
+    int32_t ldg[2];
+};
+
+template <int P0, int P1> struct Pads { static constexpr int P[2] = {P0, P1}; };
+
+// ------------------------------------------------------------------------------------------------ forward
+template <int TP, int RP>
+__global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnK a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(VK_LDS char*)smem;
+    constexpr int PADS[2] = {TP, RP};
+    constexpr int NKT[2] = {TP / 16, RP / 16};
+    const uint32_t kimg[2] = {lds0, lds0 + TP * 128};
+    const uint32_t vimg[2] = {lds0 + (TP + RP) * 128, lds0 + (TP + RP) * 128 + TP * 128};
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int b = blockIdx.x / a.nh, h = blockIdx.x - b * a.nh;
+    const int g = lane >> 4, lq = lane & 15;
+
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        if (a.gate[0][m] || a.gate[1][m]) {
+            stage_img(kimg[m], a.k[m] + ((size_t)b * a.L[m]) * a.ld[m] + h * DH, a.ld[m], a.L[m], PADS[m], tid, blockDim.x);
+            stage_img(vimg[m], a.v[m] + ((size_t)b * a.L[m]) * a.ld[m] + h * DH, a.ld[m], a.L[m], PADS[m], tid, blockDim.x);
+        }
+    }
+    __syncthreads();
+
+    const int nqt0 = (a.gate[0][0] || a.gate[0][1]) ? (a.L[0] + 15) / 16 : 0;
+    const int nqt1 = (a.gate[1][0] || a.gate[1][1]) ? (a.L[1] + 15) / 16 : 0;
+    for (int task = wave; task < nqt0 + nqt1; task += nwaves) {
+        const int mq = task < nqt0 ? 0 : 1;
+        const int qt = mq ? task - nqt0 : task;
+        const int Lq = a.L[mq];
+        const int qi = qt * 16 + lq;
+        const bool qvalid = qi < Lq;
+        const int qc = qvalid ? qi : Lq - 1;
+        const uint16_t* qrow = a.q[mq] + ((size_t)b * Lq + qc) * a.ld[mq] + h * DH;
+        const bf16x8 qf0 = *(const bf16x8*)(qrow + g * 8);
+        const bf16x8 qf1 = *(const bf16x8*)(qrow + 32 + g * 8);
+
+        f32x4 s0[NKT[0]], s1[NKT[1]];
+        float mx = -INFINITY;
+        // scores for both key modalities (uniform branches; arrays statically indexed)
+#define VK_SCORES(MK, S)                                                                                   \
+        _Pragma("unroll") for (int kt = 0; kt < NKT[MK]; ++kt) {                                           \
+            S[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};                                     \
+            if (a.gate[mq][MK] && kt * 16 < a.L[MK]) {                                                     \
+                f32x4 acc = {0.f, 0.f, 0.f, 0.f};                                                          \
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg[MK], kt * 16, 0, lane), qf0, acc, 0, 0, 0); \
+                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg[MK], kt * 16, 1, lane), qf1, acc, 0, 0, 0); \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
+                    const int key = kt * 16 + 4 * g + r;                                                   \
+                    if (key < a.L[MK]) {                                                                   \
+                        S[kt][r] = acc[r] * a.scale + a.mask[MK][(size_t)b * a.L[MK] + key];               \
+                        mx = fmaxf(mx, S[kt][r]);                                                          \
+                    }                                                                                      \
+                }                                                                                          \
+            }                                                                                              \
+        }
+        VK_SCORES(0, s0)
+        VK_SCORES(1, s1)
+#undef VK_SCORES
+        mx = group_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NKT[0]; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s0[kt][r] = __expf(s0[kt][r] - mx); sum += s0[kt][r]; }
+#pragma unroll
+        for (int kt = 0; kt < NKT[1]; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { s1[kt][r] = __expf(s1[kt][r] - mx); sum += s1[kt][r]; }
+        sum = group_sum(sum);
+        const float inv = 1.0f / sum;
+        if (qvalid && g == 0) a.lse[mq][((size_t)b * a.nh + h) * Lq + qi] = mx + __logf(sum);
+        const uint32_t drow = (uint32_t)(((size_t)b * a.nh + h) * Lq + qc);
+
+        f32x4 o[4];
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define VK_PV(MK, S)                                                                                       \
+        if (a.gate[mq][MK]) {                                                                              \
+            const vk_dropout dc = a.drop[mq][MK];                                                          \
+            const bool don = dc.threshold != 0;                                                            \
+            const uint64_t seed = don ? *dc.seed : 0;                                                      \
+            _Pragma("unroll") for (int kt = 0; kt < NKT[MK]; ++kt) {                                       \
+                u32x4 w = {~0u, ~0u, ~0u, ~0u};                                                            \
+                if (don && kt * 16 < a.L[MK])                                                              \
+                    w = philox4((uint32_t)(kt * 4 + g), drow, dc.site, 0u, (uint32_t)seed, (uint32_t)(seed >> 32)); \
+                _Pragma("unroll") for (int r = 0; r < 4; ++r)                                              \
+                    S[kt][r] = (w[r] >= dc.threshold) ? S[kt][r] * inv * dc.scale : 0.f;                   \
+            }                                                                                              \
+            _Pragma("unroll") for (int pp = 0; pp < NKT[MK] / 2; ++pp) {                                   \
+                if (pp * 32 < a.L[MK]) {                                                                   \
+                    const bf16x8 pb = pack_pair(S[2 * pp], S[2 * pp + 1]);                                 \
+                    _Pragma("unroll") for (int dt = 0; dt < 4; ++dt)                                       \
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(vimg[MK], pp * 32, dt * 16, lane), pb, o[dt], 0, 0, 0); \
+                }                                                                                          \
+            }                                                                                              \
+        }
+        VK_PV(0, s0)
+        VK_PV(1, s1)
+#undef VK_PV
+        if (qvalid) {
+            uint16_t* orow = a.ctx[mq] + ((size_t)b * Lq + qi) * a.ldo[mq] + h * DH + 4 * g;
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt)
+                *(u32x2*)(orow + dt * 16) = u32x2{pack2bf(o[dt][0], o[dt][1]), pack2bf(o[dt][2], o[dt][3])};
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ backward
+template <int TP, int RP>
+__global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnK a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(VK_LDS char*)smem;
+    constexpr int PADS[2] = {TP, RP};
+    constexpr int NKT[2] = {TP / 16, RP / 16};
+    constexpr int ROWS = TP + RP;
+    // images: Q, K, V, dO for both modalities; then lse[ROWS], delta[ROWS] floats
+    const uint32_t qimg[2] = {lds0, lds0 + TP * 128};
+    const uint32_t kimg[2] = {qimg[0] + ROWS * 128, qimg[1] + ROWS * 128};
+    const uint32_t vimg[2] = {kimg[0] + ROWS * 128, kimg[1] + ROWS * 128};
+    const uint32_t gimg[2] = {vimg[0] + ROWS * 128, vimg[1] + ROWS * 128};
+    float VK_LDS* lse_s = (float VK_LDS*)(uintptr_t)(lds0 + 4 * ROWS * 128);
+    float VK_LDS* del_s = lse_s + ROWS;
+    const int rbase[2] = {0, TP};
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int b = blockIdx.x / a.nh, h = blockIdx.x - b * a.nh;
+    const int g = lane >> 4, lq = lane & 15;
+
+    bool qact[2], kact[2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        qact[m] = a.gate[m][0] || a.gate[m][1];
+        kact[m] = a.gate[0][m] || a.gate[1][m];
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+        const size_t row0 = (size_t)b * a.L[m];
+        if (kact[m]) {
+            stage_img(kimg[m], a.k[m] + row0 * a.ld[m] + h * DH, a.ld[m], a.L[m], PADS[m], tid, blockDim.x);
+            stage_img(vimg[m], a.v[m] + row0 * a.ld[m] + h * DH, a.ld[m], a.L[m], PADS[m], tid, blockDim.x);
+        }
+        if (qact[m]) {
+            stage_img(qimg[m], a.q[m] + row0 * a.ld[m] + h * DH, a.ld[m], a.L[m], PADS[m], tid, blockDim.x);
+            stage_img(gimg[m], a.dctx[m] + row0 * a.ldo[m] + h * DH, a.ldo[m], a.L[m], PADS[m], tid, blockDim.x);
+            // delta[q] = sum_d dO[q][d] * O[q][d] (8 lanes per row), lse copy
+            for (int idx = tid; idx < PADS[m] * 8; idx += blockDim.x) {
+                const int row = idx >> 3, ch = idx & 7;
+                float part = 0.f;
+                if (row < a.L[m]) {
+                    const u32x4 dv = *(const u32x4*)(a.dctx[m] + (row0 + row) * a.ldo[m] + h * DH + ch * 8);
+                    const u32x4 ov = *(const u32x4*)(a.ctx[m] + (row0 + row) * a.ldo[m] + h * DH + ch * 8);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        part += bf2f(dv[i] & 0xFFFF) * bf2f(ov[i] & 0xFFFF) + bf2f(dv[i] >> 16) * bf2f(ov[i] >> 16);
+                }
+                part += __shfl_xor(part, 1, 64);
+                part += __shfl_xor(part, 2, 64);
+                part += __shfl_xor(part, 4, 64);
+                if (ch == 0) {
+                    del_s[rbase[m] + row] = part;
+                    lse_s[rbase[m] + row] = row < a.L[m] ? a.lse[m][((size_t)b * a.nh + h) * a.L[m] + row] : 0.f;
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    const int nkt0 = kact[0] ? (a.L[0] + 15) / 16 : 0, nkt1 = kact[1] ? (a.L[1] + 15) / 16 : 0;
+    const int nqt0 = qact[0] ? (a.L[0] + 15) / 16 : 0, nqt1 = qact[1] ? (a.L[1] + 15) / 16 : 0;
+    const int nktasks = nkt0 + nkt1, ntasks = nktasks + nqt0 + nqt1;
+    for (int task = wave; task < ntasks; task += nwaves) {
+        if (task < nktasks) {
+            // ---------------- key-tile role: dK, dV of 16 keys of modality mk ----------------
+            const int mk = task < nkt0 ? 0 : 1;
+            const int kt = mk ? task - nkt0 : task;
+            const int Lk = a.L[mk];
+            const int key = kt * 16 + lq;
+            const bool kvalid = key < Lk;
+            const float kmask = kvalid ? a.mask[mk][(size_t)b * Lk + key] : 0.f;
+            const bf16x8 kf0 = img_row_frag(kimg[mk], kt * 16, 0, lane), kf1 = img_row_frag(kimg[mk], kt * 16, 1, lane);
+            const bf16x8 vf0 = img_row_frag(vimg[mk], kt * 16, 0, lane), vf1 = img_row_frag(vimg[mk], kt * 16, 1, lane);
+            f32x4 dk[4], dv[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+#define VK_KROLE(MQ)                                                                                       \
+            if (a.gate[MQ][mk]) {                                                                          \
+                const int Lq = a.L[MQ];                                                                    \
+                const vk_dropout dc = a.drop[MQ][mk];                                                      \
+                const bool don = dc.threshold != 0;                                                        \
+                const uint64_t seed = don ? *dc.seed : 0;                                                  \
+                _Pragma("unroll") for (int pp = 0; pp < NKT[MQ] / 2; ++pp) {                               \
+                    if (pp * 32 < Lq) {                                                                    \
+                        f32x4 pd[2], ds[2];                                                                \
+                        _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                 \
+                            const int qt = pp * 2 + hh;                                                    \
+                            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};                     \
+                            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(qimg[MQ], qt * 16, 0, lane), kf0, s, 0, 0, 0); \
+                            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(qimg[MQ], qt * 16, 1, lane), kf1, s, 0, 0, 0); \
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(gimg[MQ], qt * 16, 0, lane), vf0, dp, 0, 0, 0); \
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(gimg[MQ], qt * 16, 1, lane), vf1, dp, 0, 0, 0); \
+                            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                \
+                                const int qi = qt * 16 + 4 * g + r;                                        \
+                                float p = 0.f, keep = 1.f;                                                 \
+                                if (qi < Lq && kvalid) {                                                   \
+                                    p = __expf(s[r] * a.scale + kmask - lse_s[rbase[MQ] + qi]);            \
+                                    if (don) {                                                             \
+                                        const uint32_t drow = (uint32_t)(((size_t)b * a.nh + h) * Lq + qi); \
+                                        const u32x4 w = philox4((uint32_t)(key >> 2), drow, dc.site, 0u, (uint32_t)seed, (uint32_t)(seed >> 32)); \
+                                        keep = (w[key & 3] >= dc.threshold) ? dc.scale : 0.f;              \
+                                    }                                                                      \
+                                }                                                                          \
+                                pd[hh][r] = p * keep;                                                      \
+                                ds[hh][r] = p * (dp[r] * keep - del_s[rbase[MQ] + (qi < PADS[MQ] ? qi : 0)]); \
+                            }                                                                              \
+                        }                                                                                  \
+                        const bf16x8 pb = pack_pair(pd[0], pd[1]), sb = pack_pair(ds[0], ds[1]);           \
+                        _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) {                                 \
+                            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(gimg[MQ], pp * 32, dt * 16, lane), pb, dv[dt], 0, 0, 0); \
+                            dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(qimg[MQ], pp * 32, dt * 16, lane), sb, dk[dt], 0, 0, 0); \
+                        }                                                                                  \
+                    }                                                                                      \
+                }                                                                                          \
+            }
+            VK_KROLE(0)
+            VK_KROLE(1)
+#undef VK_KROLE
+            if (kvalid) {
+                const size_t off = ((size_t)b * Lk + key) * a.ldg[mk] + h * DH + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    *(u32x2*)(a.dk[mk] + off + dt * 16) = u32x2{pack2bf(dk[dt][0] * a.scale, dk[dt][1] * a.scale), pack2bf(dk[dt][2] * a.scale, dk[dt][3] * a.scale)};
+                    *(u32x2*)(a.dv[mk] + off + dt * 16) = u32x2{pack2bf(dv[dt][0], dv[dt][1]), pack2bf(dv[dt][2], dv[dt][3])};
+                }
+            }
+        } else {
+            // ---------------- query-tile role: dQ of 16 queries of modality mq ----------------
+            const int t2 = task - nktasks;
+            const int mq = t2 < nqt0 ? 0 : 1;
+            const int qt = mq ? t2 - nqt0 : t2;
+            const int Lq = a.L[mq];
+            const int qi = qt * 16 + lq;
+            const bool qvalid = qi < Lq;
+            const bf16x8 qf0 = img_row_frag(qimg[mq], qt * 16, 0, lane), qf1 = img_row_frag(qimg[mq], qt * 16, 1, lane);
+            const bf16x8 gf0 = img_row_frag(gimg[mq], qt * 16, 0, lane), gf1 = img_row_frag(gimg[mq], qt * 16, 1, lane);
+            const float lse = lse_s[rbase[mq] + qt * 16 + lq], delta = del_s[rbase[mq] + qt * 16 + lq];
+            const uint32_t drow = (uint32_t)(((size_t)b * a.nh + h) * Lq + (qvalid ? qi : 0));
+            f32x4 dq[4];
+#pragma unroll
+            for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#define VK_QROLE(MK)                                                                                       \
+            if (a.gate[mq][MK]) {                                                                          \
+                const int Lk = a.L[MK];                                                                    \
+                const vk_dropout dc = a.drop[mq][MK];                                                      \
+                const bool don = dc.threshold != 0;                                                        \
+                const uint64_t seed = don ? *dc.seed : 0;                                                  \
+                _Pragma("unroll") for (int pp = 0; pp < NKT[MK] / 2; ++pp) {                               \
+                    if (pp * 32 < Lk) {                                                                    \
+                        f32x4 ds[2];                                                                       \
+                        _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                 \
+                            const int kt = pp * 2 + hh;                                                    \
+                            f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};                     \
+                            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg[MK], kt * 16, 0, lane), qf0, s, 0, 0, 0); \
+                            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg[MK], kt * 16, 1, lane), qf1, s, 0, 0, 0); \
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(vimg[MK], kt * 16, 0, lane), gf0, dp, 0, 0, 0); \
+                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(vimg[MK], kt * 16, 1, lane), gf1, dp, 0, 0, 0); \
+                            u32x4 w = {~0u, ~0u, ~0u, ~0u};                                                \
+                            if (don) w = philox4((uint32_t)(kt * 4 + g), drow, dc.site, 0u, (uint32_t)seed, (uint32_t)(seed >> 32)); \
+                            _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                \
+                                const int key = kt * 16 + 4 * g + r;                                       \
+                                float v = 0.f;                                                             \
+                                if (key < Lk && qvalid) {                                                  \
+                                    const float p = __expf(s[r] * a.scale + a.mask[MK][(size_t)b * Lk + key] - lse); \
+                                    const float keep = (w[r] >= dc.threshold) ? dc.scale : 0.f;            \
+                                    v = p * (dp[r] * keep - delta);                                        \
+                                }                                                                          \
+                                ds[hh][r] = v;                                                             \
+                            }                                                                              \
+                        }                                                                                  \
+                        const bf16x8 sb = pack_pair(ds[0], ds[1]);                                         \
+                        _Pragma("unroll") for (int dt = 0; dt < 4; ++dt)                                   \
+                            dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(kimg[MK], pp * 32, dt * 16, lane), sb, dq[dt], 0, 0, 0); \
+                    }                                                                                      \
+                }                                                                                          \
+            }
+            VK_QROLE(0)
+            VK_QROLE(1)
+#undef VK_QROLE
+            if (qvalid) {
+                const size_t off = ((size_t)b * Lq + qi) * a.ldg[mq] + h * DH + 4 * g;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt)
+                    *(u32x2*)(a.dq[mq] + off + dt * 16) = u32x2{pack2bf(dq[dt][0] * a.scale, dq[dt][1] * a.scale), pack2bf(dq[dt][2] * a.scale, dq[dt][3] * a.scale)};
+            }
+        }
+    }
+}
+
+static int fill(AttnK& k, const vk_attn_args* a, const vk_attn_bwd_args* bw) {
+    for (int m = 0; m < 2; ++m) {
+        k.q[m] = (const uint16_t*)a->q[m]; k.k[m] = (const uint16_t*)a->k[m]; k.v[m] = (const uint16_t*)a->v[m];
+        k.ld[m] = a->ld[m]; k.L[m] = a->L[m]; k.mask[m] = a->mask[m];
+        k.ctx[m] = (uint16_t*)a->ctx[m]; k.ldo[m] = a->ldo[m]; k.lse[m] = a->lse[m];
+        for (int n = 0; n < 2; ++n) { k.gate[m][n] = a->gate[m][n]; k.drop[m][n] = a->drop[m][n]; }
+        k.dctx[m] = bw ? (const uint16_t*)bw->dctx[m] : nullptr;
+        k.dq[m] = bw ? (uint16_t*)bw->dq[m] : nullptr; k.dk[m] = bw ? (uint16_t*)bw->dk[m] : nullptr;
+        k.dv[m] = bw ? (uint16_t*)bw->dv[m] : nullptr; k.ldg[m] = bw ? bw->ldg[m] : 0;
+    }
+    k.B = a->B; k.nh = a->nh; k.scale = a->scale;
+    for (int m = 0; m < 2; ++m) {
+        const bool qa = a->gate[m][0] || a->gate[m][1], ka = a->gate[0][m] || a->gate[1][m];
+        if (!qa && !ka) continue;
+        if (a->L[m] <= 0) return set_error("vk_gated_attn: modality %d is gated on but has length %d", m, a->L[m]);
+        if ((a->ld[m] & 7) || (a->ldo[m] & 7)) return set_error("vk_gated_attn: row strides must be multiples of 8");
+        if (ka && (!a->k[m] || !a->v[m] || !a->mask[m])) return set_error("vk_gated_attn: K/V/mask of modality %d missing", m);
+        if (qa && (!a->q[m] || !a->ctx[m] || !a->lse[m])) return set_error("vk_gated_attn: Q/ctx/lse of modality %d missing", m);
+        if (bw && qa && (!bw->dctx[m] || !bw->dq[m])) return set_error("vk_gated_attn_bwd: dctx/dq of modality %d missing", m);
+        if (bw && ka && (!bw->dk[m] || !bw->dv[m])) return set_error("vk_gated_attn_bwd: dk/dv of modality %d missing", m);
+    }
+    if (a->L[0] > 64 || a->L[1] > 128) return set_error("vk_gated_attn: lengths (%d, %d) exceed the (64, 128) tile budget", a->L[0], a->L[1]);
+    return 0;
+}
+
+template <int TP, int RP>
+static int launch_fwd(const AttnK& k, int nq_tiles, hipStream_t s) {
+    const int lds = 2 * (TP + RP) * 128;
+    int waves = nq_tiles < 1 ? 1 : (nq_tiles > 8 ? 8 : nq_tiles);
+    hipLaunchKernelGGL((attn_fwd_kernel<TP, RP>), dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
+    return check_launch("vk_gated_attn_fwd");
+}
+template <int TP, int RP>
+static int launch_bwd(const AttnK& k, int ntasks, hipStream_t s) {
+    const int lds = 4 * (TP + RP) * 128 + 2 * (TP + RP) * 4;
+    auto kern = attn_bwd_kernel<TP, RP>;
+    static bool once = false;
+    if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
+    int waves = ntasks < 1 ? 1 : (ntasks > 8 ? 8 : ntasks);
+    hipLaunchKernelGGL(kern, dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
+    return check_launch("vk_gated_attn_bwd");
+}
+
+}  // namespace vk
+
+extern "C" int vk_gated_attn_fwd(const vk_attn_args* a, vk_stream_t stream) {
+    using namespace vk;
+    AttnK k;
+    if (int rc = fill(k, a, nullptr)) return rc;
+    if (a->B <= 0) return 0;
+    int nq = 0;
+    for (int m = 0; m < 2; ++m) if (a->gate[m][0] || a->gate[m][1]) nq += (a->L[m] + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+    const bool bigT = a->L[0] > 32, bigR = a->L[1] > 64;
+    if (!bigT && !bigR) return launch_fwd<32, 64>(k, nq, s);
+    if (bigT && !bigR) return launch_fwd<64, 64>(k, nq, s);
+    if (!bigT && bigR) return launch_fwd<32, 128>(k, nq, s);
+    return launch_fwd<64, 128>(k, nq, s);
+}
+
+extern "C" int vk_gated_attn_bwd(const vk_attn_args* a, const vk_attn_bwd_args* bw, vk_stream_t stream) {
+    using namespace vk;
+    AttnK k;
+    if (int rc = fill(k, a, bw)) return rc;
+    if (a->B <= 0) return 0;
+    int nt = 0;
+    for (int m = 0; m < 2; ++m) {
+        if (a->gate[m][0] || a->gate[m][1]) nt += (a->L[m] + 15) / 16;
+        if (a->gate[0][m] || a->gate[1][m]) nt += (a->L[m] + 15) / 16;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const bool bigT = a->L[0] > 32, bigR = a->L[1] > 64;
+    if (!bigT && !bigR) return launch_bwd<32, 64>(k, nt, s);
+    if (bigT && !bigR) return launch_bwd<64, 64>(k, nt, s);
+    if (!bigT && bigR) return launch_bwd<32, 128>(k, nt, s);
+    return launch_bwd<64, 128>(k, nt, s);
+}

@@ -76,10 +76,7 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
 // ds_read_b64_tr_b16: within each group of 16 lanes, lane 4q+p supplies the address of row q,
 // elements 4p..4p+3 of a 4x16 block of 16-bit values; lane i receives column i (rows 0..3).
 __device__ __forceinline__ bf16x4 lds_read_tr16(uint32_t byte_addr) {
-    bf16x4 r;
-    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(r) : "v"(byte_addr) : "memory");
-    return r;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((VK_LDS bf16x4*)(uintptr_t)byte_addr);
 }
-__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
 }  // namespace vk

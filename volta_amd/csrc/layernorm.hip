@@ -1,0 +1,233 @@
+// Fused (dropout +) residual + LayerNorm, forward and backward, for gfx950.
+// HBM-bound row kernels: one 64-lane wave per row, 8-byte bf16x4 accesses, fp32 statistics with the
+// two-pass mean / biased variance of the reference (volta/encoders.py:57-61, eps inside the sqrt).
+// Replaces apex's cuApplyLayerNorm / cuComputeGradInput / cuComputePartGradGammaBeta
+// (apex/csrc/layer_norm_cuda_kernel.cu:279-322,523-637), which hard-code 32-lane warps, together with
+// the dropout + residual add that volta runs as separate eager ops (volta/encoders.py:410-423).
+#include "common.h"
+#include "../../include/volta_hip.h"
+#include "util.h"
+
+namespace vk {
+
+constexpr float LN_EPS = 1e-12f;
+constexpr int LN_THREADS = 256;
+constexpr int LN_BWD_ROWS = 32;     // rows per workgroup in the backward (8 per wave)
+
+__device__ __forceinline__ void load4(const uint16_t* p, float (&v)[4]) {
+    u32x2 r = *(const u32x2*)p;
+    v[0] = bf2f(r[0] & 0xFFFF); v[1] = bf2f(r[0] >> 16); v[2] = bf2f(r[1] & 0xFFFF); v[3] = bf2f(r[1] >> 16);
+}
+__device__ __forceinline__ void store4(uint16_t* p, const float (&v)[4]) {
+    *(u32x2*)p = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+}
+
+template <int NCH>
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(vk_ln_args a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.x * 4 + wave;
+    if (row >= a.M) return;
+    const int H = a.H;
+    const bool drop_on = a.drop.threshold != 0;
+    const uint64_t seed = drop_on ? *a.drop.seed : 0;
+    const uint32_t drow = row < a.split_row ? row : row - a.split_row;
+    vk_dropout dc = a.drop;
+    if (row >= a.split_row) dc.site += 1;
+    DropCfg dcfg{dc.seed, dc.site, dc.threshold, dc.scale};
+    const uint16_t* d = (const uint16_t*)a.d + (size_t)row * H;
+    const uint16_t* x = a.x ? (const uint16_t*)a.x + (size_t)row * H : nullptr;
+
+    float z[NCH][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = j * 256 + lane * 4;
+        z[j][0] = z[j][1] = z[j][2] = z[j][3] = 0.f;
+        if (c < H) {
+            load4(d + c, z[j]);
+            if (drop_on && !a.post) {
+                u32x4 w = drop_words(dcfg, seed, drow, (uint32_t)(c >> 2));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[j][r] = (w[r] >= dc.threshold) ? z[j][r] * dc.scale : 0.f;
+            }
+            if (x) {
+                float xv[4];
+                load4(x + c, xv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[j][r] += xv[r];
+            }
+            sum += z[j][0] + z[j][1] + z[j][2] + z[j][3];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)H;
+    float sq = 0.f;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = j * 256 + lane * 4;
+        if (c < H) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { const float t = z[j][r] - mean; sq += t * t; }
+        }
+    }
+    const float var = wave_sum(sq) / (float)H;
+    const float rstd = 1.0f / sqrtf(var + LN_EPS);
+    if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
+    uint16_t* y = (uint16_t*)a.y + (size_t)row * H;
+    uint16_t* zs = a.z ? (uint16_t*)a.z + (size_t)row * H : nullptr;
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int c = j * 256 + lane * 4;
+        if (c < H) {
+            const f32x4 g = *(const f32x4*)(a.gamma + c);
+            const f32x4 b = *(const f32x4*)(a.beta + c);
+            float o[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = g[r] * ((z[j][r] - mean) * rstd) + b[r];
+            if (drop_on && a.post) {
+                u32x4 w = drop_words(dcfg, seed, drow, (uint32_t)(c >> 2));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (w[r] >= dc.threshold) ? o[r] * dc.scale : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] *= a.out_scale;
+            if (zs) store4(zs + c, z[j]);
+            store4(y + c, o);
+        }
+    }
+}
+
+template <int NCH>
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(vk_ln_bwd_args a) {
+    __shared__ float red[4][2][NCH * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int H = a.H;
+    const bool drop_on = a.drop.threshold != 0;
+    const uint64_t seed = drop_on ? *a.drop.seed : 0;
+    float pg[NCH][4], pb[NCH][4];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pg[j][r] = pb[j][r] = 0.f;
+
+    for (int it = 0; it < LN_BWD_ROWS / 4; ++it) {
+        const int row = blockIdx.x * LN_BWD_ROWS + it * 4 + wave;
+        if (row >= a.M) break;
+        const uint32_t drow = row < a.split_row ? row : row - a.split_row;
+        DropCfg dcfg{a.drop.seed, a.drop.site + (row >= a.split_row ? 1u : 0u), a.drop.threshold, a.drop.scale};
+        const uint16_t* dy = (const uint16_t*)a.dy + (size_t)row * H;
+        const uint16_t* z = (const uint16_t*)a.z + (size_t)row * H;
+        const float mean = a.mean[row], rstd = a.rstd[row];
+        float xh[NCH][4], gh[NCH][4];
+        u32x4 words[NCH];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = j * 256 + lane * 4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xh[j][r] = gh[j][r] = 0.f;
+            if (c < H) {
+                float dv[4], zv[4];
+                load4(dy + c, dv);
+                load4(z + c, zv);
+                if (drop_on) words[j] = drop_words(dcfg, seed, drow, (uint32_t)(c >> 2));
+                const f32x4 g = *(const f32x4*)(a.gamma + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float gy = dv[r] * a.out_scale;
+                    if (drop_on && a.post) gy = (words[j][r] >= a.drop.threshold) ? gy * a.drop.scale : 0.f;
+                    const float xv = (zv[r] - mean) * rstd;
+                    pg[j][r] += gy * xv;
+                    pb[j][r] += gy;
+                    const float gx = gy * g[r];
+                    xh[j][r] = xv;
+                    gh[j][r] = gx;
+                    s1 += gx;
+                    s2 += gx * xv;
+                }
+            }
+        }
+        s1 = wave_sum(s1) / (float)H;
+        s2 = wave_sum(s2) / (float)H;
+        uint16_t* dz = (uint16_t*)a.dz + (size_t)row * H;
+        uint16_t* dd = a.dd ? (uint16_t*)a.dd + (size_t)row * H : nullptr;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = j * 256 + lane * 4;
+            if (c < H) {
+                float o[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = rstd * (gh[j][r] - s1 - xh[j][r] * s2);
+                store4(dz + c, o);
+                if (dd) {
+                    if (drop_on && !a.post) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = (words[j][r] >= a.drop.threshold) ? o[r] * a.drop.scale : 0.f;
+                    }
+                    store4(dd + c, o);
+                }
+            }
+        }
+    }
+    // reduce the four waves' column partials, one [2][H] record per workgroup
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            red[wave][0][j * 256 + lane * 4 + r] = pg[j][r];
+            red[wave][1][j * 256 + lane * 4 + r] = pb[j][r];
+        }
+    __syncthreads();
+    float* out = a.partial + (size_t)blockIdx.x * 2 * H;
+    for (int i = threadIdx.x; i < 2 * NCH * 256; i += LN_THREADS) {
+        const int which = i / (NCH * 256), c = i - which * NCH * 256;
+        if (c < H) out[which * H + c] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
+    }
+}
+
+__global__ void ln_bwd_finalize_kernel(const float* partial, int nblk, int H, float* dgamma, float* dbeta) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * H) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * 2 * H + i];
+    if (i < H) dgamma[i] = s; else dbeta[i - H] = s;
+}
+
+}  // namespace vk
+
+extern "C" int vk_ln_fwd(const vk_ln_args* a, vk_stream_t stream) {
+    using namespace vk;
+    if (a->H % 4 || a->H > 2048 || a->H <= 0) return set_error("vk_ln_fwd: H=%d must be a multiple of 4, <= 2048", a->H);
+    if (a->M <= 0) return 0;
+    const int nch = (a->H + 255) / 256;
+    dim3 grid((a->M + 3) / 4), block(LN_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    switch (nch) {
+        case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, s, *a); break;
+        case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, s, *a); break;
+        case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, s, *a); break;
+        case 4: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, *a); break;
+        default: hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, s, *a); break;
+    }
+    return check_launch("vk_ln_fwd");
+}
+
+extern "C" int vk_ln_bwd_partial_rows(int M) { return (M + vk::LN_BWD_ROWS - 1) / vk::LN_BWD_ROWS; }
+
+extern "C" int vk_ln_bwd(const vk_ln_bwd_args* a, vk_stream_t stream) {
+    using namespace vk;
+    if (a->H % 4 || a->H > 1024 || a->H <= 0) return set_error("vk_ln_bwd: H=%d must be a multiple of 4, <= 1024", a->H);
+    if (a->M <= 0) return 0;
+    const int nch = (a->H + 255) / 256;
+    const int nblk = vk_ln_bwd_partial_rows(a->M);
+    dim3 grid(nblk), block(LN_THREADS);
+    hipStream_t s = (hipStream_t)stream;
+    switch (nch) {
+        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, *a); break;
+        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, *a); break;
+        case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, *a); break;
+        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, *a); break;
+    }
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * a->H + 255) / 256), dim3(256), 0, s, a->partial, nblk, a->H,
+                       a->dgamma, a->dbeta);
+    return check_launch("vk_ln_bwd");
+}

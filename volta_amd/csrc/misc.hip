@@ -1,0 +1,35 @@
+// Small utility kernels: seed word, dtype casts, fills.
+#include "common.h"
+#include "../../include/volta_hip.h"
+#include "util.h"
+
+namespace vk {
+
+__global__ void set_seed_kernel(uint64_t* p, uint64_t v) { *p = v; }
+
+// fp32 -> bf16, 8 elements per lane (32-B loads, 16-B stores); n8 = n / 8, scalar tail after it
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n) {
+    const size_t n8 = n >> 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 a = *(const f32x4*)(src + i * 8), b = *(const f32x4*)(src + i * 8 + 4);
+        *(u32x4*)(dst + i * 8) = u32x4{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[n8 * 8 + threadIdx.x] = f2bf(src[n8 * 8 + threadIdx.x]);
+}
+
+}  // namespace vk
+
+extern "C" int vk_set_seed(uint64_t* seed_dev, uint64_t seed, vk_stream_t s) {
+    hipLaunchKernelGGL(vk::set_seed_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, seed_dev, seed);
+    return vk::check_launch("vk_set_seed");
+}
+
+extern "C" int vk_cast_f32_bf16(const float* src, void* dst, int64_t n, vk_stream_t s) {
+    if (n <= 0) return 0;
+    if (((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return vk::set_error("vk_cast_f32_bf16: 16-byte alignment required");
+    int64_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(vk::cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, src, (uint16_t*)dst, (size_t)n);
+    return vk::check_launch("vk_cast_f32_bf16");
+}

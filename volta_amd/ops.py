@@ -1,0 +1,139 @@
+"""Thin tensor-level wrappers over the C ABI (one call = one kernel launch on the current stream).
+Used by the parity tests and by the plan builder; they validate shapes on the host because a wrong
+shape in a hand-written kernel is a GPU fault, not an exception."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import _lib as L_
+from ._lib import check, ptr, stream_ptr
+
+
+def _bf16(t):
+    assert t.dtype == torch.bfloat16 and t.is_cuda, "bf16 cuda tensor expected"
+    return t
+
+
+def gemm_problem(A, B, Cout, layout, M, N, K, bias=None, R=None, C2=None, bias_grad=None, dyn=None, n_store=0,
+                 lda=None, ldb=None, ldc=None, ldr=None):
+    """Builds one vk_gemm_problem after checking that every operand really covers what the kernel reads."""
+    lda = lda if lda is not None else A.stride(-2)
+    ldb = ldb if ldb is not None else B.stride(-2)
+    ldc = ldc if ldc is not None else Cout.stride(-2)
+    a_rows, a_cols = (K, M) if layout == L.TN else (M, K)
+    b_rows, b_cols = (N, K) if layout == L.NT else (K, N)
+    for name, t, rows, cols, ld in (("A", A, a_rows, a_cols, lda), ("B", B, b_rows, b_cols, ldb)):
+        _bf16(t)
+        need = (rows - 1) * ld + cols if rows > 0 else 0
+        have = t.numel() - 0 if t.is_contiguous() else t.untyped_storage().nbytes() // 2 - t.storage_offset()
+        assert need <= have, "%s operand too small: need %d elements, have %d" % (name, need, have)
+    ncols = max(N, n_store)
+    need_c = (M - 1) * ldc + ncols if M > 0 else 0
+    have_c = Cout.untyped_storage().nbytes() // Cout.element_size() - Cout.storage_offset()
+    assert need_c <= have_c, "C too small: need %d have %d" % (need_c, have_c)
+    if bias is not None:
+        assert bias.dtype == torch.float32 and bias.numel() >= N
+    if R is not None:
+        _bf16(R)
+        ldr = ldr if ldr is not None else R.stride(-2)
+        assert (M - 1) * ldr + N <= R.untyped_storage().nbytes() // 2 - R.storage_offset()
+    if bias_grad is not None:
+        assert bias_grad.dtype == torch.float32 and bias_grad.numel() >= M
+    if dyn is not None:
+        assert dyn.dtype == torch.int32
+    return L.GemmProblem(ptr(A), ptr(B), ptr(Cout), ptr(C2), ptr(bias), ptr(R), ptr(bias_grad), ptr(dyn),
+                         M, N, K, lda, ldb, ldc, ldr or 0, n_store)
+
+
+def gemm_grouped(layout, epilogue, problems):
+    arr = (L.GemmProblem * len(problems))(*problems)
+    check(L.lib.vk_gemm_grouped(layout, epilogue, arr, len(problems), stream_ptr()))
+
+
+def cast_f32_bf16(src, dst):
+    assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
+    check(L.lib.vk_cast_f32_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr()))
+
+
+def set_seed(seed_t, value):
+    assert seed_t.dtype == torch.int64 and seed_t.is_cuda
+    check(L.lib.vk_set_seed(ptr(seed_t), C.c_uint64(value & 0xFFFFFFFFFFFFFFFF), stream_ptr()))
+
+
+def ln_fwd(d, x, gamma, beta, y, z, mean, rstd, M, H, drop=None, split_row=None, post=0, out_scale=1.0):
+    for t in (d, y):
+        _bf16(t)
+        assert t.numel() >= M * H
+    assert gamma.dtype == torch.float32 and gamma.numel() == H and beta.numel() == H
+    assert mean.numel() >= M and rstd.numel() >= M and mean.dtype == torch.float32
+    a = L.LnArgs(ptr(d), ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(z), ptr(mean), ptr(rstd), M, H,
+                 split_row if split_row is not None else M, post, out_scale, drop or L.dropout_cfg(None, 0, 0.0))
+    check(L.lib.vk_ln_fwd(C.byref(a), stream_ptr()))
+
+
+def ln_bwd(dy, z, mean, rstd, gamma, dz, dd, partial, dgamma, dbeta, M, H, drop=None, split_row=None, post=0,
+           out_scale=1.0):
+    for t in (dy, z, dz):
+        _bf16(t)
+        assert t.numel() >= M * H
+    assert partial.numel() >= L.lib.vk_ln_bwd_partial_rows(M) * 2 * H and partial.dtype == torch.float32
+    assert dgamma.numel() == H and dbeta.numel() == H
+    a = L.LnBwdArgs(ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(dz), ptr(dd), ptr(partial), ptr(dgamma),
+                    ptr(dbeta), M, H, split_row if split_row is not None else M, post, out_scale,
+                    drop or L.dropout_cfg(None, 0, 0.0))
+    check(L.lib.vk_ln_bwd(C.byref(a), stream_ptr()))
+
+
+def attn_args(qkv, L, masks, ctx, lse, B, nh, gate, drops=None, H=None):
+    """qkv[m]: [B*L[m], 3H] fused projection output (Q | K | V column blocks); ctx[m]: [B*L[m], H]."""
+    a = L_.AttnArgs()
+    H = H or nh * 64
+    for m in range(2):
+        used_q = gate[m][0] or gate[m][1]
+        used_k = gate[0][m] or gate[1][m]
+        if not (used_q or used_k):
+            continue
+        t = _bf16(qkv[m])
+        assert t.shape == (B * L[m], 3 * H) and t.is_contiguous()
+        es = 2
+        a.q[m] = t.data_ptr()
+        a.k[m] = t.data_ptr() + H * es
+        a.v[m] = t.data_ptr() + 2 * H * es
+        a.ld[m] = 3 * H
+        a.L[m] = L[m]
+        if used_k:
+            assert masks[m].dtype == torch.float32 and masks[m].shape == (B, L[m]) and masks[m].is_contiguous()
+            a.mask[m] = masks[m].data_ptr()
+        if used_q:
+            assert _bf16(ctx[m]).shape == (B * L[m], H) and lse[m].numel() == B * nh * L[m] and lse[m].dtype == torch.float32
+            a.ctx[m] = ctx[m].data_ptr()
+            a.ldo[m] = H
+            a.lse[m] = lse[m].data_ptr()
+    a.B, a.nh, a.scale = B, nh, 0.125
+    for i in range(2):
+        for j in range(2):
+            a.gate[i][j] = int(bool(gate[i][j]))
+            a.drop[i][j] = drops[i][j] if drops is not None else L_.dropout_cfg(None, 0, 0.0)
+    a._refs = (qkv, masks, ctx, lse)      # the struct only holds raw pointers: keep the tensors alive
+    return a
+
+
+def attn_fwd(a):
+    check(L_.lib.vk_gated_attn_fwd(C.byref(a), stream_ptr()))
+
+
+def attn_bwd(a, dctx, dqkv, L, B, gate, H):
+    b = L_.AttnBwdArgs()
+    for m in range(2):
+        if gate[m][0] or gate[m][1]:
+            assert _bf16(dctx[m]).shape == (B * L[m], H)
+            b.dctx[m] = dctx[m].data_ptr()
+        if gate[m][0] or gate[m][1] or gate[0][m] or gate[1][m]:
+            t = _bf16(dqkv[m])
+            assert t.shape == (B * L[m], 3 * H) and t.is_contiguous()
+            b.dq[m] = t.data_ptr()
+            b.dk[m] = t.data_ptr() + H * 2
+            b.dv[m] = t.data_ptr() + 2 * H * 2
+            b.ldg[m] = 3 * H
+    check(L_.lib.vk_gated_attn_bwd(C.byref(a), C.byref(b), stream_ptr()))
