@@ -1,0 +1,228 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: one full pre-training step (forward + backward + grad-norm clip + AdamW
+[+ gradient all-reduce]) of BertForVLPreTraining on synthetic ConceptualCaptions-shaped batches.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched through torch.distributed.run)
+
+Prints ONE JSON line (rank 0): image-text pairs/s over all GPUs, the MFMA roofline of the step and of the
+GEMM kernel family (timed live with HIP events on the launch stream), and a CPU baseline (the fp32 oracle
+of oracle/volta_ref.py on the host cores, bounded sample)."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# matmul FLOPs per image-text pair, forward + backward, measured on the reference graph
+GFLOP_PER_PAIR = {("ctrl_vilbert_base", 20, 36): 37.876, ("ctrl_vilbert_base", 38, 36): 54.420, ("ctrl_lxmert", 20, 36): 35.415,
+                  ("ctrl_uniter_base", 20, 36): 32.937, ("ctrl_visualbert_base", 20, 36): 32.937, ("ctrl_vl-bert_base", 20, 100): 69.184}
+PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="ctrl_vilbert_base")
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--seq-len", type=int, default=20)
+    ap.add_argument("--regions", type=int, default=36)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def gemm_flops(eng, plan):
+    """Algorithmic FLOPs (2 M N K) of every GEMM op in a plan; device-side row counts are read back."""
+    from volta_amd import _lib as L
+    out = {}
+    for i, (kind, layout, epi, nprob, arr, _, _) in enumerate(plan.ops):
+        if kind != L.OP_GEMM:
+            continue
+        fl = 0.0
+        for j in range(nprob):
+            q = arr[j]
+            M, K = q.M, q.K
+            if q.dyn:
+                n = int(_dev_int(q.dyn, eng).item())
+                if layout == L.TN:
+                    K = min(K, n)
+                else:
+                    M = min(M, n)
+            fl += 2.0 * M * q.N * K
+        out[i] = fl
+    return out
+
+
+def _dev_int(addr, eng):
+    for name in ("n_t", "n_v"):
+        if eng.bufs[name].data_ptr() == addr:
+            return eng.bufs[name].cpu()
+    raise KeyError(addr)
+
+
+def cpu_baseline(cfg_name, T, R, budget_s=25.0):
+    """fp32 oracle (the reference's arithmetic in stock torch CPU ops): forward + backward + AdamW, B = 32."""
+    from oracle import volta_ref as Rf
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    torch.set_num_threads(max(1, min(ncpu, 16)))      # the GPU box grants a 16-CPU share per GPU
+    print("[bench] cpu baseline on %d threads" % torch.get_num_threads(), file=sys.stderr, flush=True)
+    cfg = Rf.RefConfig.from_json_file(os.path.join(ROOT, "config", cfg_name + ".json"))
+    sd = Rf.make_weights(cfg, seed=1, std=0.02)
+    aliases = Rf.param_aliases(cfg)
+    leaves = {k: v.requires_grad_(True) for k, v in sd.items() if k not in aliases}
+    full = dict(leaves)
+    for a, t in aliases.items():
+        full[a] = leaves[t]
+    m = {k: torch.zeros_like(v) for k, v in leaves.items()}
+    v2 = {k: torch.zeros_like(v) for k, v in leaves.items()}
+    B = 32
+    batch = Rf.synthetic_batch(cfg, B, T, R, seed=3)
+    times = []
+    t_start = time.time()
+    for step in range(1, 5):
+        t0 = time.time()
+        lm, img, nsp = Rf.forward_from_batch(full, cfg, batch, train=True)
+        for p in leaves.values():
+            p.grad = None
+        (lm + img + nsp).sum().backward()
+        grads = [p.grad for p in leaves.values()]
+        Rf.clip_grad_norm(grads, 5.0)
+        with torch.no_grad():
+            for k, p in leaves.items():
+                Rf.adamw_step(p, p.grad, m[k], v2[k], step, 1e-4, 0.9, 0.999, 1e-6, 0.01 if Rf.decays(k) else 0.0)
+        times.append(time.time() - t0)
+        print("[bench] cpu step %d: %.2f s" % (step, times[-1]), file=sys.stderr, flush=True)
+        if time.time() - t_start > budget_s and len(times) >= 2:
+            break
+    timed = times[1:] if len(times) > 1 else times
+    return dict(value=B * len(timed) / sum(timed), unit="image-text pairs/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d timed steps (after 1 warm-up) of fwd+bwd+clip+AdamW, fp32 oracle, B=32, T=%d, R=%d, %s" % (len(timed), T, R, cfg_name))
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from volta_amd.config import BertConfig
+    from volta_amd.modeling import BertForVLPreTraining
+    from volta_amd.optimization import AdamW, WarmupLinearSchedule, clip_grad_norm_
+    from volta_amd.parallel import DistributedDataParallel
+    from volta_amd.data import synthetic_batch, model_args
+    from volta_amd import _lib as L
+
+    cfg = BertConfig.from_json_file(os.path.join(ROOT, "config", a.config + ".json"))
+    torch.manual_seed(1234)
+    model = BertForVLPreTraining(cfg).cuda()
+    model.train()
+    model.materialize()
+    net = DistributedDataParallel(model) if world > 1 else model
+    no_decay = ("bias", "LayerNorm.bias", "LayerNorm.weight")
+    groups = [{"params": [p], "lr": 1e-4, "weight_decay": 0.0 if any(nd in n for nd in no_decay) else 0.01}
+              for n, p in model.named_parameters()]                       # one group per parameter (train_concap.py:213-224)
+    opt = AdamW(groups, lr=1e-4, eps=1e-6, betas=(0.9, 0.999))
+    sched = WarmupLinearSchedule(opt, warmup_steps=100, t_total=100000)
+    batch = synthetic_batch(cfg, a.batch, a.seq_len, a.regions, seed=1234 + rank)
+    args = model_args(batch)
+
+    def step():
+        lm, img, nsp = net(*args)
+        loss = lm + img + nsp
+        loss.backward()
+        clip_grad_norm_(model.parameters(), 5.0, defer_to_optimizer=True)
+        opt.step()
+        sched.step()
+        opt.zero_grad()
+        return lm, img, nsp
+
+    for _ in range(a.warmup):
+        losses = step()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        losses = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    ms = elapsed * 1e3 / a.steps
+    pairs_s = a.batch * world * a.steps / elapsed
+    gflop = GFLOP_PER_PAIR.get((a.config, a.seq_len, a.regions))
+    out = {"metric": "image-text pairs/sec, %s pretrain step" % a.config, "value": pairs_s, "unit": "image-text pairs/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "config": {"workload": "%s pretrain step (fwd+bwd+clip+AdamW%s), per-GPU batch %d, T=%d, %d regions (+1 global), objective 1, dropout on"
+                      % (a.config, "+allreduce" if world > 1 else "", a.batch, a.seq_len, a.regions),
+                      "global_batch": a.batch * world, "seq_len": a.seq_len, "regions": a.regions, "parallelism": "dp%d" % world},
+           "losses_last_step": [float(x) for x in losses]}
+    if rank == 0:
+        print("[bench] timed region done: %.3f ms/step, %.1f pairs/s" % (ms, pairs_s), file=sys.stderr, flush=True)
+        if gflop is not None:
+            ach = pairs_s / world * gflop / 1e3            # per-GPU TFLOP/s
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+                               "traffic": None, "scope": "whole step: pairs/s x %.3f GFLOP/pair (reference-graph matmul FLOPs, BASELINE.md)" % gflop}
+        if not a.no_kernel_timing:
+            eng = model._last[0]
+            eng.fwd.enable_timing(True)
+            eng.bwd.enable_timing(True)
+            nprof = 3
+            for _ in range(nprof):
+                step()
+            torch.cuda.synchronize()
+            fl = dict(("f%d" % i, v) for i, v in gemm_flops(eng, eng.fwd).items())
+            fl.update(("b%d" % i, v) for i, v in gemm_flops(eng, eng.bwd).items())
+            tms = dict(("f%d" % i, eng.fwd.timing[i] / nprof) for i in range(len(eng.fwd.ops)))
+            tms.update(("b%d" % i, eng.bwd.timing[i] / nprof) for i in range(len(eng.bwd.ops)))
+            gemm_ms = sum(tms[k] for k in fl)
+            gemm_fl = sum(fl.values())
+            kinds = {}
+            for plan, tag in ((eng.fwd, "f"), (eng.bwd, "b")):
+                for i, op in enumerate(plan.ops):
+                    name = {L.OP_GEMM: "gemm", L.OP_LN_FWD: "ln_fwd", L.OP_LN_BWD: "ln_bwd", L.OP_ATTN_FWD: "attn_fwd", L.OP_ATTN_BWD: "attn_bwd"}.get(op[0], "other")
+                    kinds[name] = kinds.get(name, 0.0) + tms["%s%d" % (tag, i)]
+            eng.fwd.enable_timing(False)
+            eng.bwd.enable_timing(False)
+            ach = gemm_fl / (gemm_ms * 1e-3) / 1e12
+            out["roofline"]["dominant_kernel"] = {
+                "name": "vk::gemm_kernel (bf16 MFMA 16x16x32, all layouts/epilogues)", "launches_per_step": len(fl),
+                "algorithmic_gflop_per_step": gemm_fl / 1e9, "ms_per_step": gemm_ms, "avg_launch_us": gemm_ms * 1e3 / len(fl),
+                "achieved": ach, "frac": ach / PEAK_BF16_TFLOPS, "timing": "HIP events on the launch stream, %d profiled steps" % nprof}
+            out["kernel_ms_per_step"] = {k: round(v, 3) for k, v in sorted(kinds.items(), key=lambda kv: -kv[1])}
+        if world == 1 and not a.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(a.config, a.seq_len, a.regions)
+            except Exception as e:      # the baseline must never take the GPU number down with it
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -58,7 +58,8 @@ enum {
     VK_EPI_MULR = 2,  /* C(bf16) = acc * R                                  (gelu backward)  */
     VK_EPI_ADDR = 3,  /* C(bf16) = acc + bias + R                           (grad accumulate)*/
     VK_EPI_F32 = 4,   /* C(fp32) = acc + bias, columns [N, n_store) written as 0           */
-    VK_EPI_RELU = 5   /* C(bf16) = max(acc + bias, 0)                       (poolers)        */
+    VK_EPI_RELU = 5,  /* C(bf16) = max(acc + bias, 0)                       (poolers)        */
+    VK_EPI_F32_ACC = 6 /* C(fp32) += acc, bias_grad += ...  (wgrad of weights shared by two modalities) */
 };
 typedef struct vk_gemm_problem {
     const void* A;
@@ -82,23 +83,32 @@ int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* probs, int 
  * (apex/csrc/layer_norm_cuda.cpp:121-240: forward_affine / backward_affine) and the python fallback
  * BertLayerNorm (volta/encoders.py:48-61) together with the dropout and residual add that precede
  * it (volta/encoders.py:410-423, 552-565).  eps = 1e-12 inside the sqrt, biased variance, fp32 stats.
- *   z = drop_pre(d) + x ;  y = drop_post(gamma * (z - mean) * rstd + beta)
- * Rows [0, split_row) use drop.site, rows >= split_row use drop.site + 1 with row index restarting at
- * 0 (the reference draws separate masks for the text and vision tensors of a shared sub-layer). */
+ *   z = drop_pre(d) + x + addvec ;  y = drop_post(gamma * (z - mean) * rstd + beta) * out_scale
+ * Dropout row index: rows [0, split_row) belong to segment 0, the rest to segment 1 (the reference
+ * draws separate masks for the text and vision tensors of a shared sub-layer, or one mask over their
+ * per-sample concatenation in the single-stream embeddings).  With r' = row - segment start the Philox
+ * row is (r' / div) * mul + (r' % div) + off  (div == 0: r' itself). */
+typedef struct vk_drop_rows {
+    uint32_t site;
+    int32_t div, mul, off;
+} vk_drop_rows;
 typedef struct vk_ln_args {
     const void* d;         /* bf16 [M, H]  dense output (bias already added)                    */
     const void* x;         /* bf16 [M, H]  residual input or NULL                                */
+    const float* addvec;   /* fp32 [H] added to every row before the statistics, or NULL         */
     const float* gamma;    /* [H] */
     const float* beta;     /* [H] */
     void* y;               /* bf16 [M, H]                                                       */
     void* z;               /* bf16 [M, H]  pre-LN activations saved for backward (may alias d)  */
     float* mean;           /* [M] */
     float* rstd;           /* [M] */
+    const int32_t* dyn;    /* device row count overriding M when non-NULL                        */
     int32_t M, H;
     int32_t split_row;     /* >= M when unused */
     int32_t post;          /* 0: dropout on d before the add; 1: dropout on the LN output        */
-    float out_scale;       /* y is multiplied by this after LN (LXMERT's (a+b)/2); normally 1    */
-    vk_dropout drop;
+    float out_scale;       /* normally 1 (LXMERT image embedding: 0.5)                            */
+    vk_dropout drop;       /* seed / threshold / scale; drop.site is ignored, see seg[]           */
+    vk_drop_rows seg[2];
 } vk_ln_args;
 int vk_ln_fwd(const vk_ln_args* a, vk_stream_t s);
 
@@ -108,16 +118,19 @@ typedef struct vk_ln_bwd_args {
     const float* mean;
     const float* rstd;
     const float* gamma;
-    void* dz;              /* bf16 [M, H]: gradient w.r.t. z (= gradient of the residual branch)  */
-    void* dd;              /* bf16 [M, H]: gradient w.r.t. d (dropout mask re-applied); may be NULL when no dropout */
+    void* dz;              /* bf16 [M, H]: gradient w.r.t. z (= gradient of the residual branch and of addvec rows) */
+    void* dd;              /* bf16 [M, H]: gradient w.r.t. d (pre-dropout mask re-applied); NULL: not needed */
     float* partial;        /* workspace fp32 [vk_ln_bwd_partial_rows(M), 2, H] */
     float* dgamma;         /* [H] */
     float* dbeta;          /* [H] */
+    const int32_t* dyn;
     int32_t M, H;
     int32_t split_row;
     int32_t post;
     float out_scale;
+    int32_t accumulate;    /* != 0: dgamma / dbeta += (shared sub-layers: one LayerNorm, two modalities) */
     vk_dropout drop;
+    vk_drop_rows seg[2];
 } vk_ln_bwd_args;
 int vk_ln_bwd_partial_rows(int M);
 int vk_ln_bwd(const vk_ln_bwd_args* a, vk_stream_t s);
@@ -158,6 +171,158 @@ typedef struct vk_attn_bwd_args {
 int vk_gated_attn_fwd(const vk_attn_args* a, vk_stream_t s);
 /* `a` must be the forward call's arguments (ctx and lse now inputs). */
 int vk_gated_attn_bwd(const vk_attn_args* a, const vk_attn_bwd_args* b, vk_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Embeddings.  vk_embed_sum_fwd replaces the three nn.Embedding lookups and their sum in
+ * BertEmbeddings.forward (volta/embeddings.py:55-66; also :345-348, :442-445); the LayerNorm +
+ * dropout that follow are vk_ln_fwd (post = 1).  pos_ids == NULL means position = row % T. */
+typedef struct vk_embed_args {
+    const int64_t* ids;       /* [M] */
+    const int64_t* type_ids;  /* [M] or NULL (all 0) */
+    const int64_t* pos_ids;   /* [M] or NULL */
+    const float* word;        /* [V, H] fp32 master weights */
+    const float* pos;         /* [P, H] */
+    const float* type;        /* [n_types, H] */
+    const void* extra;        /* bf16 [M, H] added per row, or NULL (VL-BERT visual part) */
+    void* z;                  /* bf16 [M, H] out */
+    int32_t M, T, H;
+    int32_t V, P, n_types;    /* table heights: indices are clamped into range (no device fault on bad ids) */
+} vk_embed_args;
+int vk_embed_sum_fwd(const vk_embed_args* a, vk_stream_t s);
+/* Backward of the lookups (autograd of nn.Embedding): dword / dtype (and dpos when pos_ids != NULL) are
+ * ACCUMULATED with atomics (caller zeroes them, or lets the tied LM-decoder wgrad write dword first);
+ * with implicit positions dpos rows [0, T) are overwritten. */
+typedef struct vk_embed_bwd_args {
+    const void* dz;           /* bf16 [M, H] */
+    const int64_t* ids;
+    const int64_t* type_ids;
+    const int64_t* pos_ids;
+    float* dword;
+    float* dpos;
+    float* dtype;             /* may be NULL */
+    int32_t M, T, H, n_types;
+    int32_t V, P;
+} vk_embed_bwd_args;
+int vk_embed_sum_bwd(const vk_embed_bwd_args* a, vk_stream_t s);
+
+/* Box-location linear (nn.Linear(num_locs=5, H), volta/embeddings.py:135,141,157,164,420,450): fp32 in,
+ * bf16 out; backward gives dW [H, nloc] and db [H] (partial: fp32 [vk_rows32(M), 9, H] workspace). */
+int vk_rows32(int M);
+int vk_loc_linear_fwd(const float* loc, const float* W, const float* bias, void* out, int M, int H, int nloc, vk_stream_t s);
+int vk_loc_linear_bwd(const void* dz, const float* loc, float* partial, float* dW, float* db, int M, int H, int nloc, vk_stream_t s);
+/* y = dropout((a + b) * scale)  (LXMERT image embedding, embeddings.py:169-170); backward != 0:
+ * y = a * keep * scale (b ignored). */
+int vk_add_dropout(const void* a, const void* b, void* y, int M, int H, float scale, vk_dropout drop, int backward, vk_stream_t s);
+/* out[c] (+)= sum_m src[m][c]; partial: fp32 [vk_rows32(M), H]. */
+int vk_colsum_bf16(const void* src, float* partial, float* out, int M, int H, int accumulate, vk_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Heads and losses, evaluated on labelled rows only.  Replaces BertPreTrainingHeads + the loss code of
+ * BertForVLPreTraining.forward (volta/encoders.py:766-784, 1079-1109) and kl_1601 (volta/losses.py:16-22),
+ * including the two host synchronisations at encoders.py:1089 and :1111 (counts stay on the device). */
+/* flag(i) = labels[i] != -1 (mode 0) | labels[i] == 1 (mode 1).  For the j-th flagged i:
+ * pos[j] = i, rows[j] = (i / inner) * outer + (i % inner) + off; *count = number flagged. */
+int vk_select_rows(const int64_t* labels, int N, int mode, int inner, int outer, int off, int32_t* rows, int32_t* pos,
+                   int32_t* count, vk_stream_t s);
+int vk_gather_rows(const void* src, const int32_t* rows, const int32_t* count, void* dst, int H, int max_rows, vk_stream_t s);
+int vk_scatter_rows_add(const void* src, const int32_t* rows, const int32_t* count, void* dst, int H, int max_rows, vk_stream_t s);
+typedef struct vk_xent_args {
+    const float* logits;      /* fp32 [rows, ld] */
+    const int64_t* labels;    /* label of row i = labels[pos ? pos[i] : i] */
+    const int32_t* pos;       /* or NULL */
+    const int32_t* count;     /* device row count, or NULL: max_rows rows */
+    float* lse;               /* [rows] saved */
+    float* loss_sum;          /* accumulated (atomicAdd): zero it first */
+    int32_t V, ld, max_rows;
+} vk_xent_args;
+int vk_xent_fwd(const vk_xent_args* a, vk_stream_t s);
+/* dlogits(bf16)[i][c] = (softmax - onehot) * (*gscale) / count; columns [V, ldd) are written as 0 */
+int vk_xent_bwd(const vk_xent_args* a, void* dlogits, int ldd, const float* gscale, vk_stream_t s);
+typedef struct vk_kl_args {
+    const float* logits;      /* fp32 [rows, ld] */
+    const float* target;      /* fp32 [*, V]: row pos[i] is the target distribution of row i */
+    const int32_t* pos;
+    const int32_t* count;
+    float* lse;
+    float* tsum;
+    float* loss_sum;
+    float weight;             /* visual_target_weights["0"] */
+    int32_t V, ld, max_rows;
+} vk_kl_args;
+int vk_kl_fwd(const vk_kl_args* a, vk_stream_t s);
+int vk_kl_bwd(const vk_kl_args* a, void* dlogits, int ldd, const float* gscale, vk_stream_t s);
+/* losses[0] = sums[0] / *n_t ; losses[1] = w * sums[1] / max(*n_v, 1) ; losses[2] = sums[2] / B */
+int vk_loss_finalize(const float* sums, const int32_t* n_t, const int32_t* n_v, int B, float kl_weight, float* losses, vk_stream_t s);
+/* pooled = dropout(pooled_t * pooled_v) (encoders.py:769-770) and its backward through the two ReLUs */
+int vk_pool_mul_fwd(const void* pt, const void* pv, void* out, int B, int P, vk_dropout drop, vk_stream_t s);
+int vk_pool_mul_bwd(const void* dp, int ldp, const void* pt, const void* pv, void* dyt, void* dyv, int B, int P, vk_dropout drop, vk_stream_t s);
+/* additive attention mask (1 - m) * -10000 (encoders.py:983-991) */
+int vk_mask_prep(const int64_t* mask, float* out, int n, vk_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Optimizer over flat fp32 arenas.  vk_grad_norm_clip replaces torch.nn.utils.clip_grad_norm_
+ * (train_concap.py:307-308): out[0] = ||g|| * pre_scale, out[1] = min(1, max_norm / (norm + 1e-6)) stay on
+ * the device.  vk_adamw_step replaces pytorch_transformers.optimization.AdamW.step (train_concap.py:227,310;
+ * package pinned at 1.1.0 in requirements.txt:39, not vendored):
+ *   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr_c * step_mult * m / (sqrt(v) + eps) ; p -= lr_c * wd_c * p
+ * with g pre-multiplied by grad_scale * clip[1]; step_mult = sqrt(1-b2^t)/(1-b1^t) (correct_bias) or 1.
+ * Arena length is a multiple of 1024; chunk_class[i] selects (lr multiplier, weight decay) of chunk i. */
+int vk_grad_norm_workspace_floats(void);
+int vk_grad_norm_clip(const float* g, int64_t n, float pre_scale, float max_norm, float* partial, float* out, vk_stream_t s);
+typedef struct vk_adamw_args {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    void* shadow;               /* bf16 copy of p, refreshed in the same pass, or NULL */
+    const uint8_t* chunk_class; /* [n / 1024] or NULL (class 0) */
+    const float* clip;          /* device float[2] from vk_grad_norm_clip or NULL */
+    int64_t n;
+    float cls_lr_mult[8];
+    float cls_wd[8];
+    float lr, beta1, beta2, eps, step_mult, grad_scale;
+} vk_adamw_args;
+int vk_adamw_step(const vk_adamw_args* a, vk_stream_t s);
+int vk_axpy_f32(float* y, const float* x, float alpha, int64_t n, vk_stream_t s);
+int vk_memset_async(void* p, int value, int64_t bytes, vk_stream_t s);
+
+/* out[i] = a[i] * b[i] (bf16); processes rows * row_len elements where rows = min(*dyn_rows, n / row_len)
+ * when dyn_rows != NULL.  (d gelu(u) = dz * gelu'(u) in the prediction-head transforms.) */
+int vk_mul_bf16(const void* a, const void* b, void* out, int64_t n, const int32_t* dyn_rows, int row_len, vk_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Command lists.  A plan is an array of vk_op whose argument structs live in caller memory; vk_run_ops
+ * issues them in order on one stream (stops at the first error).  There is no reference counterpart:
+ * the reference walks a Python module tree and autograd graph every step (volta/encoders.py:868-881). */
+enum {
+    VK_OP_GEMM = 1,      /* a = vk_gemm_problem[i2], i0 = layout, i1 = epilogue */
+    VK_OP_LN_FWD, VK_OP_LN_BWD, VK_OP_ATTN_FWD,
+    VK_OP_ATTN_BWD,      /* a = vk_attn_args, b = vk_attn_bwd_args */
+    VK_OP_EMBED_FWD, VK_OP_EMBED_BWD, VK_OP_XENT_FWD,
+    VK_OP_XENT_BWD,      /* a = vk_xent_args, b = dlogits, i0 = ldd, c = gscale */
+    VK_OP_KL_FWD, VK_OP_KL_BWD,
+    VK_OP_GENERIC        /* a = vk_generic_args */
+};
+enum {
+    VK_FN_CAST = 1, VK_FN_MEMSET, VK_FN_LOC_FWD, VK_FN_LOC_BWD, VK_FN_ADD_DROPOUT, VK_FN_COLSUM, VK_FN_SELECT,
+    VK_FN_GATHER, VK_FN_SCATTER_ADD, VK_FN_LOSS_FINAL, VK_FN_POOL_FWD, VK_FN_POOL_BWD, VK_FN_MASK_PREP, VK_FN_MUL
+};
+typedef struct vk_generic_args {   /* positional arguments of the small entry points, see executor.cpp */
+    int32_t fn;
+    void* p[6];
+    int64_t n[6];
+    float f[2];
+    vk_dropout drop;
+} vk_generic_args;
+typedef struct vk_op {
+    int32_t kind, i0, i1, i2;
+    const void* a;
+    const void* b;
+    const void* c;
+} vk_op;
+int vk_run_ops(const vk_op* ops, int n, vk_stream_t s);
+/* Same, bracketing each op with HIP events on `s`; synchronises `s` and adds elapsed ms per op to ms[0..n). */
+int vk_run_ops_timed(const vk_op* ops, int n, vk_stream_t s, float* ms);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,156 @@
+"""End-to-end parity of the HIP engine behind BertForVLPreTraining against the CPU oracle: hidden states after
+every sub-layer, the three losses and the gradient of every parameter; eval mode and training mode with the
+Philox dropout masks replayed in the oracle.  True layer widths (768 / 12 heads / 3072), reduced depth.  GPU only."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BASE = dict(vocab_size=3000, hidden_size=768, num_attention_heads=12, intermediate_size=3072, pooler_size=1024,
+            max_position_embeddings=64, type_vocab_size=2, num_locs=5, add_global_imgfeat="first", v_feature_size=256,
+            v_hidden_size=768, v_num_attention_heads=12, v_intermediate_size=3072, v_pooler_size=1024,
+            visual_target_weights={"0": 1.0}, fusion_method="mul", v_initializer_range=0.02)
+SINGLE = dict(tt_attn_sublayers=[0, 2], tv_attn_sublayers=[0, 2], vt_attn_sublayers=[0, 2], vv_attn_sublayers=[0, 2],
+              t_ff_sublayers=[1, 3], v_ff_sublayers=[1, 3], shared_sublayers=[0, 1, 2, 3], single_ln_sublayers=[0, 1, 2, 3])
+CONFIGS = {
+    "vilbert": dict(BASE, image_embeddings="vilbert", tt_attn_sublayers=[0, 6], t_ff_sublayers=[1, 3, 5, 7], tv_attn_sublayers=[2],
+                    vt_attn_sublayers=[2], vv_attn_sublayers=[6], v_ff_sublayers=[3, 7], tt_attn_sublayers_extra=None),
+    "lxmert": dict(BASE, image_embeddings="lxmert", tt_attn_sublayers=[0, 2, 5], vv_attn_sublayers=[0, 5], tv_attn_sublayers=[4],
+                   vt_attn_sublayers=[4], shared_sublayers=[4], t_ff_sublayers=[1, 3, 6], v_ff_sublayers=[1, 6]),
+    "uniter": dict(BASE, image_embeddings="uniter", **SINGLE),
+    "visualbert": dict(BASE, image_embeddings="visualbert", **SINGLE),
+    "gated": dict(BASE, image_embeddings="vilbert", tt_attn_sublayers=[0], tv_attn_sublayers=[0], vt_attn_sublayers=[0],
+                  vv_attn_sublayers=[0], t_ff_sublayers=[1], v_ff_sublayers=[1]),
+}
+CONFIGS["vilbert"].pop("tt_attn_sublayers_extra")
+CONFIGS["vilbert"]["tt_attn_sublayers"] = [0, 4, 6]
+CONFIGS["vilbert"]["t_ff_sublayers"] = [1, 3, 5, 7]
+CONFIGS["vilbert"]["vv_attn_sublayers"] = [6]
+CONFIGS["vilbert"]["v_ff_sublayers"] = [3, 7]
+
+
+def build(name, seed=2):
+    from oracle import volta_ref as R
+    from volta_amd.config import BertConfig
+    from volta_amd.modeling import BertForVLPreTraining
+    cd = CONFIGS[name]
+    rcfg = R.RefConfig(cd)
+    sd = R.make_weights(rcfg, seed=seed, std=0.04)
+    model = BertForVLPreTraining(BertConfig.from_dict(cd))
+    model.load_state_dict(sd, strict=True)
+    return model.cuda(), rcfg, sd
+
+
+def rel_err(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+@pytest.mark.parametrize("name", list(CONFIGS))
+@pytest.mark.parametrize("train", [False, True])
+def test_forward_backward_parity(name, train):
+    from oracle import volta_ref as R
+    model, rcfg, sd = build(name)
+    B, T, Rn = 4, 20, 36
+    batch = R.synthetic_batch(rcfg, B, T, Rn, seed=7, pad=True)
+    seed = 0xABCDEF12345
+    model.train(train)
+    model.set_dropout_seed(seed)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    lm, img, nsp = model(cb["input_ids"], cb["image_feat"], cb["image_loc"], cb["segment_ids"], cb["input_mask"], cb["image_mask"],
+                         cb["lm_label_ids"], cb["image_label"], cb["image_cls"], None, None, None, None, None, cb["is_match"])
+    torch.cuda.synchronize()
+    eng = model._last[0]
+    # oracle (fp32, CPU) with the same weights; training mode replays the engine's Philox masks
+    aliases = R.param_aliases(rcfg)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k not in aliases}
+    full = dict(leaves)
+    for a, t in aliases.items():
+        full[a] = leaves[t]
+    taps = {}
+    olm, oimg, onsp = R.forward_from_batch(full, rcfg, batch, train=train, philox_seed=seed if train else None, taps=taps)
+    # ---- hidden states after the embeddings and after every sub-layer, pooled vectors
+    for key, ref in taps.items():
+        if key not in eng.taps or ref is None or ref.dim() < 2:
+            continue
+        got = eng.taps[key].float().cpu().view(ref.shape)
+        e = rel_err(got, ref.detach())
+        assert e < 2e-2, (name, key, e)
+    # ---- losses.  Tolerances (bf16 activations, fp32 accumulation): MLM / region / total loss 2e-3 relative;
+    # the ITM loss averages only B = 4 samples of bf16-noisy logits here (1e-2), it tightens as 1/sqrt(B).
+    for got, ref, nm in ((lm, olm, "lm"), (img, oimg, "img"), (nsp, onsp, "nsp")):
+        g, r = float(got.detach()), float(ref.detach())
+        tol = 1e-2 if nm == "nsp" else 2e-3
+        assert abs(g - r) <= tol * max(abs(r), 1e-3) + 2e-4, (name, nm, g, r)
+    tot, rtot = float((lm + img + nsp).detach()), float((olm + oimg + onsp).detach())
+    assert abs(tot - rtot) <= 2e-3 * abs(rtot), (name, "total loss", tot, rtot)
+    # ---- gradients of every parameter: once for the MLM + region losses, once for the ITM loss (whose
+    # gradient flows through B x 2 logits only, so the forward bf16 noise shows up as a common scale error)
+    named = dict(model.named_parameters())
+    for which, tol, min_cos in (("lm+img", 4e-2, 0.999), ("nsp", 0.3, 0.96)):
+        for p in named.values():
+            p.grad = None
+        for leaf in leaves.values():
+            leaf.grad = None
+        if which == "nsp":
+            nsp.sum().backward()
+            onsp.sum().backward()
+        else:
+            (lm + img).sum().backward(retain_graph=True)
+            (olm + oimg).sum().backward(retain_graph=True)
+        torch.cuda.synchronize()
+        bad = []
+        for k, leaf in leaves.items():
+            g_ref = leaf.grad if leaf.grad is not None else torch.zeros_like(leaf)
+            g_got = named[k].grad.float().cpu()
+            assert torch.isfinite(g_got).all(), (name, k)
+            if float(g_ref.norm()) < 1e-6:          # exactly-zero gradients (key biases: softmax shift invariance)
+                if float(g_got.norm()) > 5e-3:
+                    bad.append((k, "expected ~0", float(g_got.norm())))
+                continue
+            e = rel_err(g_got, g_ref)
+            cos = float((g_got * g_ref).sum() / (g_got.norm() * g_ref.norm()))
+            qk = ("query." in k or "key." in k) and which != "nsp"   # flows through P*(dP - delta): cancellation-prone
+            if e > (0.1 if qk else tol) or cos < (0.995 if qk else min_cos):
+                bad.append((k, e, cos, float(g_ref.norm())))
+        assert not bad, (name, train, which, bad[:12], len(bad))
+
+
+def test_no_labelled_rows_edge_case():
+    """A batch whose pairs are all mismatched carries no MLM / region labels (train_concap.py:279-284): the reference
+    then returns NaN for the MLM mean over an empty set and 0 for the region loss; gradients stay finite here."""
+    from oracle import volta_ref as R
+    model, rcfg, sd = build("vilbert")
+    batch = R.synthetic_batch(rcfg, 2, 20, 36, seed=5)
+    assert int((batch["lm_label_ids"] != -1).sum()) == 0
+    model.eval()
+    cb = {k: v.cuda() for k, v in batch.items()}
+    lm, img, nsp = model(cb["input_ids"], cb["image_feat"], cb["image_loc"], cb["segment_ids"], cb["input_mask"], cb["image_mask"],
+                         cb["lm_label_ids"], cb["image_label"], cb["image_cls"], None, None, None, None, None, cb["is_match"])
+    assert torch.isnan(lm).all() and float(img) == 0.0 and float(nsp) > 0
+    nsp.sum().backward()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_grad_accumulation_and_state_dict_roundtrip():
+    from oracle import volta_ref as R
+    model, rcfg, sd = build("gated")
+    batch = R.synthetic_batch(rcfg, 2, 20, 36, seed=7)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    model.eval()
+
+    def step():
+        out = model(cb["input_ids"], cb["image_feat"], cb["image_loc"], cb["segment_ids"], cb["input_mask"], cb["image_mask"],
+                    cb["lm_label_ids"], cb["image_label"], cb["image_cls"], None, None, None, None, None, cb["is_match"])
+        sum(out).sum().backward()
+
+    step()
+    g1 = {k: p.grad.clone() for k, p in model.named_parameters()}
+    step()                       # second backward without zero_grad: gradients add up
+    torch.cuda.synchronize()
+    for k, p in model.named_parameters():
+        assert torch.allclose(p.grad, 2 * g1[k], rtol=1e-4, atol=1e-6), k
+    back = model.state_dict()
+    for k, v in sd.items():
+        assert torch.equal(back[k].cpu(), v), k

@@ -4,6 +4,8 @@ or `make -C volta_amd/csrc`)."""
 import ctypes as C
 import os
 
+import torch  # noqa: F401  -- must come first: libvolta_hip.so has to bind to the HIP runtime torch already loaded
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvolta_hip.so")
 
@@ -39,16 +41,62 @@ class GemmProblem(C.Structure):
                 ("ldr", i32), ("n_store", i32)]
 
 
+class DropRows(C.Structure):
+    _fields_ = [("site", C.c_uint32), ("div", i32), ("mul", i32), ("off", i32)]
+
+
 class LnArgs(C.Structure):
-    _fields_ = [("d", c_p), ("x", c_p), ("gamma", c_p), ("beta", c_p), ("y", c_p), ("z", c_p), ("mean", c_p),
-                ("rstd", c_p), ("M", i32), ("H", i32), ("split_row", i32), ("post", i32), ("out_scale", C.c_float),
-                ("drop", Dropout)]
+    _fields_ = [("d", c_p), ("x", c_p), ("addvec", c_p), ("gamma", c_p), ("beta", c_p), ("y", c_p), ("z", c_p),
+                ("mean", c_p), ("rstd", c_p), ("dyn", c_p), ("M", i32), ("H", i32), ("split_row", i32), ("post", i32),
+                ("out_scale", C.c_float), ("drop", Dropout), ("seg", DropRows * 2)]
 
 
 class LnBwdArgs(C.Structure):
     _fields_ = [("dy", c_p), ("z", c_p), ("mean", c_p), ("rstd", c_p), ("gamma", c_p), ("dz", c_p), ("dd", c_p),
-                ("partial", c_p), ("dgamma", c_p), ("dbeta", c_p), ("M", i32), ("H", i32), ("split_row", i32),
-                ("post", i32), ("out_scale", C.c_float), ("drop", Dropout)]
+                ("partial", c_p), ("dgamma", c_p), ("dbeta", c_p), ("dyn", c_p), ("M", i32), ("H", i32),
+                ("split_row", i32), ("post", i32), ("out_scale", C.c_float), ("accumulate", i32), ("drop", Dropout),
+                ("seg", DropRows * 2)]
+
+
+class EmbedArgs(C.Structure):
+    _fields_ = [("ids", c_p), ("type_ids", c_p), ("pos_ids", c_p), ("word", c_p), ("pos", c_p), ("type", c_p),
+                ("extra", c_p), ("z", c_p), ("M", i32), ("T", i32), ("H", i32), ("V", i32), ("P", i32), ("n_types", i32)]
+
+
+class EmbedBwdArgs(C.Structure):
+    _fields_ = [("dz", c_p), ("ids", c_p), ("type_ids", c_p), ("pos_ids", c_p), ("dword", c_p), ("dpos", c_p),
+                ("dtype", c_p), ("M", i32), ("T", i32), ("H", i32), ("n_types", i32), ("V", i32), ("P", i32)]
+
+
+class XentArgs(C.Structure):
+    _fields_ = [("logits", c_p), ("labels", c_p), ("pos", c_p), ("count", c_p), ("lse", c_p), ("loss_sum", c_p),
+                ("V", i32), ("ld", i32), ("max_rows", i32)]
+
+
+class KlArgs(C.Structure):
+    _fields_ = [("logits", c_p), ("target", c_p), ("pos", c_p), ("count", c_p), ("lse", c_p), ("tsum", c_p),
+                ("loss_sum", c_p), ("weight", C.c_float), ("V", i32), ("ld", i32), ("max_rows", i32)]
+
+
+class AdamwArgs(C.Structure):
+    _fields_ = [("p", c_p), ("g", c_p), ("m", c_p), ("v", c_p), ("shadow", c_p), ("chunk_class", c_p), ("clip", c_p),
+                ("n", C.c_int64), ("cls_lr_mult", C.c_float * 8), ("cls_wd", C.c_float * 8), ("lr", C.c_float),
+                ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("step_mult", C.c_float),
+                ("grad_scale", C.c_float)]
+
+
+class GenericArgs(C.Structure):
+    _fields_ = [("fn", i32), ("p", c_p * 6), ("n", C.c_int64 * 6), ("f", C.c_float * 2), ("drop", Dropout)]
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", i32), ("i0", i32), ("i1", i32), ("i2", i32), ("a", c_p), ("b", c_p), ("c", c_p)]
+
+
+(OP_GEMM, OP_LN_FWD, OP_LN_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_EMBED_FWD, OP_EMBED_BWD, OP_XENT_FWD, OP_XENT_BWD,
+ OP_KL_FWD, OP_KL_BWD, OP_GENERIC) = range(1, 13)
+(FN_CAST, FN_MEMSET, FN_LOC_FWD, FN_LOC_BWD, FN_ADD_DROPOUT, FN_COLSUM, FN_SELECT, FN_GATHER, FN_SCATTER_ADD,
+ FN_LOSS_FINAL, FN_POOL_FWD, FN_POOL_BWD, FN_MASK_PREP, FN_MUL) = range(1, 15)
 
 
 class AttnArgs(C.Structure):
@@ -62,7 +110,7 @@ class AttnBwdArgs(C.Structure):
 
 
 NT, NN, TN = 0, 1, 2
-EPI_BF16, EPI_GELU, EPI_MULR, EPI_ADDR, EPI_F32, EPI_RELU = range(6)
+EPI_BF16, EPI_GELU, EPI_MULR, EPI_ADDR, EPI_F32, EPI_RELU, EPI_F32_ACC = range(7)
 
 
 def _sig(name, restype, *argtypes):
@@ -83,6 +131,40 @@ _sig("vk_gated_attn_bwd", C.c_int, C.POINTER(AttnArgs), C.POINTER(AttnBwdArgs), 
 _sig("vk_ln_fwd", C.c_int, C.POINTER(LnArgs), c_p)
 _sig("vk_ln_bwd_partial_rows", C.c_int, C.c_int)
 _sig("vk_ln_bwd", C.c_int, C.POINTER(LnBwdArgs), c_p)
+_sig("vk_embed_sum_fwd", C.c_int, C.POINTER(EmbedArgs), c_p)
+_sig("vk_embed_sum_bwd", C.c_int, C.POINTER(EmbedBwdArgs), c_p)
+_sig("vk_rows32", C.c_int, C.c_int)
+_sig("vk_loc_linear_fwd", C.c_int, c_p, c_p, c_p, c_p, C.c_int, C.c_int, C.c_int, c_p)
+_sig("vk_loc_linear_bwd", C.c_int, c_p, c_p, c_p, c_p, c_p, C.c_int, C.c_int, C.c_int, c_p)
+_sig("vk_add_dropout", C.c_int, c_p, c_p, c_p, C.c_int, C.c_int, C.c_float, Dropout, C.c_int, c_p)
+_sig("vk_colsum_bf16", C.c_int, c_p, c_p, c_p, C.c_int, C.c_int, C.c_int, c_p)
+_sig("vk_select_rows", C.c_int, c_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_p, c_p, c_p, c_p)
+_sig("vk_gather_rows", C.c_int, c_p, c_p, c_p, c_p, C.c_int, C.c_int, c_p)
+_sig("vk_scatter_rows_add", C.c_int, c_p, c_p, c_p, c_p, C.c_int, C.c_int, c_p)
+_sig("vk_xent_fwd", C.c_int, C.POINTER(XentArgs), c_p)
+_sig("vk_xent_bwd", C.c_int, C.POINTER(XentArgs), c_p, C.c_int, c_p, c_p)
+_sig("vk_kl_fwd", C.c_int, C.POINTER(KlArgs), c_p)
+_sig("vk_kl_bwd", C.c_int, C.POINTER(KlArgs), c_p, C.c_int, c_p, c_p)
+_sig("vk_loss_finalize", C.c_int, c_p, c_p, c_p, C.c_int, C.c_float, c_p, c_p)
+_sig("vk_pool_mul_fwd", C.c_int, c_p, c_p, c_p, C.c_int, C.c_int, Dropout, c_p)
+_sig("vk_pool_mul_bwd", C.c_int, c_p, C.c_int, c_p, c_p, c_p, c_p, C.c_int, C.c_int, Dropout, c_p)
+_sig("vk_mask_prep", C.c_int, c_p, c_p, C.c_int, c_p)
+_sig("vk_mul_bf16", C.c_int, c_p, c_p, c_p, C.c_int64, c_p, C.c_int, c_p)
+_sig("vk_grad_norm_workspace_floats", C.c_int)
+_sig("vk_grad_norm_clip", C.c_int, c_p, C.c_int64, C.c_float, C.c_float, c_p, c_p, c_p)
+_sig("vk_adamw_step", C.c_int, C.POINTER(AdamwArgs), c_p)
+_sig("vk_axpy_f32", C.c_int, c_p, c_p, C.c_float, C.c_int64, c_p)
+_sig("vk_memset_async", C.c_int, c_p, C.c_int, C.c_int64, c_p)
+_sig("vk_run_ops", C.c_int, C.POINTER(Op), C.c_int, c_p)
+_sig("vk_run_ops_timed", C.c_int, C.POINTER(Op), C.c_int, c_p, C.POINTER(C.c_float))
+
+EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_cast_f32_bf16", "vk_gemm_grouped",
+           "vk_ln_fwd", "vk_ln_bwd_partial_rows", "vk_ln_bwd", "vk_gated_attn_fwd", "vk_gated_attn_bwd",
+           "vk_embed_sum_fwd", "vk_embed_sum_bwd", "vk_rows32", "vk_loc_linear_fwd", "vk_loc_linear_bwd",
+           "vk_add_dropout", "vk_colsum_bf16", "vk_select_rows", "vk_gather_rows", "vk_scatter_rows_add", "vk_xent_fwd",
+           "vk_xent_bwd", "vk_kl_fwd", "vk_kl_bwd", "vk_loss_finalize", "vk_pool_mul_fwd", "vk_pool_mul_bwd",
+           "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_adamw_step",
+           "vk_axpy_f32", "vk_memset_async", "vk_run_ops", "vk_run_ops_timed"]
 
 
 def check(rc):
@@ -91,7 +173,6 @@ def check(rc):
 
 
 def stream_ptr():
-    import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 

@@ -1,0 +1,325 @@
+// Embedding-side kernels (HBM-bound, one wave per row, 8/16-byte accesses):
+//   * text embedding sum  word[ids] + pos[t] + type[seg] (+ extra)        volta/embeddings.py:55-66
+//   * its backward: scatter-add into the three tables
+//   * the 5-wide box-location linear and its backward                     volta/embeddings.py:135,141
+//   * y = dropout((a + b) * scale) and its backward (LXMERT image embedding, embeddings.py:169-170)
+//   * column sums of a bf16 matrix (gradient of a broadcast row vector)
+#include "common.h"
+#include "../../include/volta_hip.h"
+#include "util.h"
+
+namespace vk {
+
+__device__ __forceinline__ void ld4(const uint16_t* p, float (&v)[4]) {
+    u32x2 r = *(const u32x2*)p;
+    v[0] = bf2f(r[0] & 0xFFFF); v[1] = bf2f(r[0] >> 16); v[2] = bf2f(r[1] & 0xFFFF); v[3] = bf2f(r[1] >> 16);
+}
+__device__ __forceinline__ void st4(uint16_t* p, const float (&v)[4]) {
+    *(u32x2*)p = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+}
+
+__device__ __forceinline__ int64_t clampi(int64_t v, int n) { return v < 0 ? 0 : (v >= n ? n - 1 : v); }
+
+__global__ __launch_bounds__(256) void embed_sum_fwd_kernel(vk_embed_args a) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= a.M) return;
+    const int64_t id = clampi(a.ids[row], a.V);
+    const int64_t ty = a.type_ids ? clampi(a.type_ids[row], a.n_types) : 0;
+    const int64_t ps = clampi(a.pos_ids ? a.pos_ids[row] : (row % a.T), a.P);
+    const float* w = a.word + (size_t)id * a.H;
+    const float* p = a.pos + (size_t)ps * a.H;
+    const float* t = a.type + (size_t)ty * a.H;
+    for (int c = lane * 4; c < a.H; c += 256) {
+        const f32x4 wv = *(const f32x4*)(w + c), pv = *(const f32x4*)(p + c), tv = *(const f32x4*)(t + c);
+        float o[4] = {wv[0] + pv[0] + tv[0], wv[1] + pv[1] + tv[1], wv[2] + pv[2] + tv[2], wv[3] + pv[3] + tv[3]};
+        if (a.extra) {
+            float e[4];
+            ld4((const uint16_t*)a.extra + (size_t)row * a.H + c, e);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] += e[r];
+        }
+        st4((uint16_t*)a.z + (size_t)row * a.H + c, o);
+    }
+}
+
+// word table: atomics (rows collide only on repeated ids); type table (<= 4 rows, every row of the batch
+// hits them): per-workgroup partial sums first, one atomic per workgroup and column afterwards.
+template <int NCH>
+__global__ __launch_bounds__(256) void embed_scatter_kernel(vk_embed_bwd_args a) {
+    __shared__ float red[4][4][NCH * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float ta[4][NCH][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ta[k][j][r] = 0.f;
+    for (int it = 0; it < 8; ++it) {
+        const int row = blockIdx.x * 32 + it * 4 + wave;
+        if (row >= a.M) break;
+        const int64_t id = clampi(a.ids[row], a.V);
+        const int ty = a.type_ids ? (int)clampi(a.type_ids[row], a.n_types) : 0;
+        const int64_t ps = a.pos_ids ? clampi(a.pos_ids[row], a.P) : -1;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = j * 256 + lane * 4;
+            if (c < a.H) {
+                float v[4];
+                ld4((const uint16_t*)a.dz + (size_t)row * a.H + c, v);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    atomicAdd(a.dword + (size_t)id * a.H + c + r, v[r]);
+                    if (ps >= 0) atomicAdd(a.dpos + (size_t)ps * a.H + c + r, v[r]);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) ta[k][j][r] += (ty == k) ? v[r] : 0.f;
+                }
+            }
+        }
+    }
+    if (!a.dtype) return;
+    for (int k = 0; k < 4 && k < a.n_types; ++k) {
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][k][j * 256 + lane * 4 + r] = ta[k][j][r];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < a.n_types * a.H; i += 256) {
+        const int k = i / a.H, c = i - k * a.H;
+        const float s = red[0][k][c] + red[1][k][c] + red[2][k][c] + red[3][k][c];
+        if (s != 0.f) atomicAdd(a.dtype + (size_t)k * a.H + c, s);
+    }
+}
+
+// dpos[t][c] = sum_b dz[(b*T + t)*H + c]   (implicit positions: t = row % T); overwrites rows [0, T)
+__global__ __launch_bounds__(64) void embed_pos_reduce_kernel(const uint16_t* dz, float* dpos, int B, int T, int H) {
+    const int t = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x * 4;
+    if (c >= H) return;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int b = 0; b < B; ++b) {
+        float v[4];
+        ld4(dz + ((size_t)b * T + t) * H + c, v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] += v[r];
+    }
+    *(f32x4*)(dpos + (size_t)t * H + c) = f32x4{s[0], s[1], s[2], s[3]};
+}
+
+// out[m][n] = sum_k loc[m][k] W[n][k] + b[n],  k < nloc <= 8, all fp32 in, bf16 out
+__global__ __launch_bounds__(256) void loc_linear_fwd_kernel(const float* loc, const float* W, const float* bias, uint16_t* out,
+                                                             int M, int H, int nloc) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    float l[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) l[k] = k < nloc ? loc[(size_t)row * nloc + k] : 0.f;
+    for (int c = lane * 4; c < H; c += 256) {
+        float o[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float s = bias[c + r];
+            for (int k = 0; k < nloc; ++k) s += l[k] * W[(size_t)(c + r) * nloc + k];
+            o[r] = s;
+        }
+        st4(out + (size_t)row * H + c, o);
+    }
+}
+
+// partial[blk][k][n] = sum over the block's 32 rows of dz[m][n] * loc[m][k] (k < nloc) and of dz[m][n] (k = nloc)
+template <int NCH>
+__global__ __launch_bounds__(256) void loc_linear_bwd_kernel(const uint16_t* dz, const float* loc, float* partial, int M, int H, int nloc) {
+    __shared__ float red[4][NCH * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[9][NCH][4];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[k][j][r] = 0.f;
+    for (int it = 0; it < 8; ++it) {
+        const int row = blockIdx.x * 32 + it * 4 + wave;
+        if (row >= M) break;
+        float l[9];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) l[k] = k < nloc ? loc[(size_t)row * nloc + k] : 0.f;
+        l[8] = 1.f;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = j * 256 + lane * 4;
+            if (c < H) {
+                float v[4];
+                ld4(dz + (size_t)row * H + c, v);
+#pragma unroll
+                for (int k = 0; k < 9; ++k)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[k][j][r] += v[r] * l[k];
+            }
+        }
+    }
+    float* out = partial + (size_t)blockIdx.x * 9 * H;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[wave][j * 256 + lane * 4 + r] = acc[k][j][r];
+        __syncthreads();
+        for (int c = threadIdx.x; c < H; c += 256) out[k * H + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+    }
+}
+// dW[n][k] = sum_blk partial[blk][k][n] ; db[n] = sum_blk partial[blk][8][n]
+__global__ void loc_linear_bwd_finalize_kernel(const float* partial, int nblk, int H, int nloc, float* dW, float* db) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 9 * H) return;
+    const int k = i / H, n = i - k * H;
+    if (k < 8 && k >= nloc) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * 9 * H + i];
+    if (k == 8) db[n] = s; else dW[(size_t)n * nloc + k] = s;
+}
+
+// y = dropout((a + b) * scale) ; backward g = dy * keep * scale   (row = m, column = c)
+__global__ __launch_bounds__(256) void add_dropout_kernel(const uint16_t* a, const uint16_t* b, uint16_t* y, int M, int H, float scale,
+                                                          vk_dropout dc, int bwd) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const bool don = dc.threshold != 0;
+    const uint64_t seed = don ? *dc.seed : 0;
+    for (int c = lane * 4; c < H; c += 256) {
+        float v[4];
+        ld4(a + (size_t)row * H + c, v);
+        if (!bwd && b) {
+            float w[4];
+            ld4(b + (size_t)row * H + c, w);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] += w[r];
+        }
+        u32x4 wd = {~0u, ~0u, ~0u, ~0u};
+        if (don) wd = philox4((uint32_t)(c >> 2), (uint32_t)row, dc.site, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = (wd[r] >= dc.threshold) ? v[r] * scale * dc.scale : 0.f;
+        st4(y + (size_t)row * H + c, v);
+    }
+}
+
+// partial[blk][c] = sum of the block's 32 rows
+template <int NCH>
+__global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* src, float* partial, int M, int H) {
+    __shared__ float red[4][NCH * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[NCH][4];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] = 0.f;
+    for (int it = 0; it < 8; ++it) {
+        const int row = blockIdx.x * 32 + it * 4 + wave;
+        if (row >= M) break;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = j * 256 + lane * 4;
+            if (c < H) {
+                float v[4];
+                ld4(src + (size_t)row * H + c, v);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[j][r] += v[r];
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][j * 256 + lane * 4 + r] = acc[j][r];
+    __syncthreads();
+    for (int c = threadIdx.x; c < H; c += 256) partial[(size_t)blockIdx.x * H + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+__global__ void colsum_finalize_kernel(const float* partial, int nblk, int H, float* out, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= H) return;
+    float s = 0.f;
+    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * H + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+}  // namespace vk
+
+using namespace vk;
+
+extern "C" int vk_embed_sum_fwd(const vk_embed_args* a, vk_stream_t s) {
+    if (a->H % 4) return set_error("vk_embed_sum_fwd: H %% 4 != 0");
+    if (a->M <= 0) return 0;
+    hipLaunchKernelGGL(embed_sum_fwd_kernel, dim3((a->M + 3) / 4), dim3(256), 0, (hipStream_t)s, *a);
+    return check_launch("vk_embed_sum_fwd");
+}
+
+extern "C" int vk_embed_sum_bwd(const vk_embed_bwd_args* a, vk_stream_t s) {
+    if (a->H % 4 || a->H > 1024) return set_error("vk_embed_sum_bwd: H must be a multiple of 4, <= 1024");
+    if (a->n_types > 4) return set_error("vk_embed_sum_bwd: at most 4 token types");
+    if (a->M <= 0) return 0;
+    const int nch = (a->H + 255) / 256;
+    dim3 grid((a->M + 31) / 32), block(256);
+    hipStream_t st = (hipStream_t)s;
+    switch (nch) {
+        case 1: hipLaunchKernelGGL(embed_scatter_kernel<1>, grid, block, 0, st, *a); break;
+        case 2: hipLaunchKernelGGL(embed_scatter_kernel<2>, grid, block, 0, st, *a); break;
+        case 3: hipLaunchKernelGGL(embed_scatter_kernel<3>, grid, block, 0, st, *a); break;
+        default: hipLaunchKernelGGL(embed_scatter_kernel<4>, grid, block, 0, st, *a); break;
+    }
+    if (!a->pos_ids && a->dpos) {
+        if (a->M % a->T) return set_error("vk_embed_sum_bwd: M %% T != 0");
+        hipLaunchKernelGGL(embed_pos_reduce_kernel, dim3(a->T, (a->H + 255) / 256), dim3(64), 0, st, (const uint16_t*)a->dz, a->dpos,
+                           a->M / a->T, a->T, a->H);
+    }
+    return check_launch("vk_embed_sum_bwd");
+}
+
+extern "C" int vk_loc_linear_fwd(const float* loc, const float* W, const float* bias, void* out, int M, int H, int nloc, vk_stream_t s) {
+    if (nloc > 8 || H % 4) return set_error("vk_loc_linear_fwd: nloc <= 8, H %% 4 == 0 required");
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(loc_linear_fwd_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)s, loc, W, bias, (uint16_t*)out, M, H, nloc);
+    return check_launch("vk_loc_linear_fwd");
+}
+
+extern "C" int vk_rows32(int M) { return (M + 31) / 32; }
+
+extern "C" int vk_loc_linear_bwd(const void* dz, const float* loc, float* partial, float* dW, float* db, int M, int H, int nloc, vk_stream_t s) {
+    if (nloc > 8 || H % 4 || H > 1024) return set_error("vk_loc_linear_bwd: nloc <= 8, H %% 4 == 0, H <= 1024 required");
+    if (M <= 0) return 0;
+    const int nblk = (M + 31) / 32, nch = (H + 255) / 256;
+    hipStream_t st = (hipStream_t)s;
+    switch (nch) {
+        case 1: hipLaunchKernelGGL(loc_linear_bwd_kernel<1>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)dz, loc, partial, M, H, nloc); break;
+        case 2: hipLaunchKernelGGL(loc_linear_bwd_kernel<2>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)dz, loc, partial, M, H, nloc); break;
+        case 3: hipLaunchKernelGGL(loc_linear_bwd_kernel<3>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)dz, loc, partial, M, H, nloc); break;
+        default: hipLaunchKernelGGL(loc_linear_bwd_kernel<4>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)dz, loc, partial, M, H, nloc); break;
+    }
+    hipLaunchKernelGGL(loc_linear_bwd_finalize_kernel, dim3((9 * H + 255) / 256), dim3(256), 0, st, partial, nblk, H, nloc, dW, db);
+    return check_launch("vk_loc_linear_bwd");
+}
+
+extern "C" int vk_add_dropout(const void* a, const void* b, void* y, int M, int H, float scale, vk_dropout drop, int backward, vk_stream_t s) {
+    if (H % 4) return set_error("vk_add_dropout: H %% 4 != 0");
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(add_dropout_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)s, (const uint16_t*)a, (const uint16_t*)b,
+                       (uint16_t*)y, M, H, scale, drop, backward);
+    return check_launch("vk_add_dropout");
+}
+
+extern "C" int vk_colsum_bf16(const void* src, float* partial, float* out, int M, int H, int accumulate, vk_stream_t s) {
+    if (H % 4 || H > 1024) return set_error("vk_colsum_bf16: H must be a multiple of 4, <= 1024");
+    if (M <= 0) return 0;
+    const int nblk = (M + 31) / 32, nch = (H + 255) / 256;
+    hipStream_t st = (hipStream_t)s;
+    switch (nch) {
+        case 1: hipLaunchKernelGGL(colsum_kernel<1>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)src, partial, M, H); break;
+        case 2: hipLaunchKernelGGL(colsum_kernel<2>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)src, partial, M, H); break;
+        case 3: hipLaunchKernelGGL(colsum_kernel<3>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)src, partial, M, H); break;
+        default: hipLaunchKernelGGL(colsum_kernel<4>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)src, partial, M, H); break;
+    }
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((H + 255) / 256), dim3(256), 0, st, partial, nblk, H, out, accumulate);
+    return check_launch("vk_colsum_bf16");
+}

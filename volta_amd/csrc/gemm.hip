@@ -167,7 +167,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const KGroup g) {
     const int gq = lane >> 4, lr = lane & 15;
     const int Mout = AT ? P.M : M;     // TN: M is the output row count and is never dynamic
     const int N = P.N;
-    const int nlim = (EPI == VK_EPI_F32 && P.n_store > N) ? P.n_store : N;
+    const int nlim = ((EPI == VK_EPI_F32 || EPI == VK_EPI_F32_ACC) && P.n_store > N) ? P.n_store : N;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + lr;
@@ -183,10 +183,14 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const KGroup g) {
             }
             const size_t off = (size_t)m * P.ldc + n;
             const bool full = (n + 3 < nlim);
-            if (EPI == VK_EPI_F32) {
+            if (EPI == VK_EPI_F32 || EPI == VK_EPI_F32_ACC) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (n + r >= N) v[r] = 0.f;
                 float* c = (float*)P.C + off;
+                if (EPI == VK_EPI_F32_ACC) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < nlim) v[r] += c[r];
+                }
                 if (full) *(f32x4*)c = f32x4{v[0], v[1], v[2], v[3]};
                 else
 #pragma unroll
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const KGroup g) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int m = m0 + wm * 64 + i * 16 + lr;
-            if (m < Mout) P.bias_grad[m] = accb[i][0];
+            if (m < Mout) P.bias_grad[m] = (EPI == VK_EPI_F32_ACC ? P.bias_grad[m] : 0.f) + accb[i][0];
         }
     }
 }
@@ -245,7 +249,7 @@ static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s) {
         break;                                                                                            \
     }
     switch (epi) {
-        VK_CASE(VK_EPI_BF16) VK_CASE(VK_EPI_GELU) VK_CASE(VK_EPI_MULR) VK_CASE(VK_EPI_ADDR) VK_CASE(VK_EPI_F32) VK_CASE(VK_EPI_RELU)
+        VK_CASE(VK_EPI_BF16) VK_CASE(VK_EPI_GELU) VK_CASE(VK_EPI_MULR) VK_CASE(VK_EPI_ADDR) VK_CASE(VK_EPI_F32) VK_CASE(VK_EPI_RELU) VK_CASE(VK_EPI_F32_ACC)
         default: return set_error("vk_gemm_grouped: unknown epilogue %d", epi);
     }
 #undef VK_CASE
@@ -265,7 +269,7 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
         if (q.M < 0 || q.N <= 0 || q.K < 0) return set_error("vk_gemm_grouped: bad shape %d %d %d", q.M, q.N, q.K);
         if ((q.lda & 7) || (q.ldb & 7)) return set_error("vk_gemm_grouped: lda/ldb must be multiples of 8 (got %d %d)", q.lda, q.ldb);
         if (((uintptr_t)q.A & 15) || ((uintptr_t)q.B & 15) || ((uintptr_t)q.C & 15)) return set_error("vk_gemm_grouped: operands must be 16-byte aligned");
-        if (epilogue != VK_EPI_F32 && (q.ldc & 3)) return set_error("vk_gemm_grouped: ldc must be a multiple of 4");
+        if (epilogue != VK_EPI_F32 && epilogue != VK_EPI_F32_ACC && (q.ldc & 3)) return set_error("vk_gemm_grouped: ldc must be a multiple of 4");
         if (layout != VK_TN && (q.K % 64) != 0 && q.lda < ((q.K + 63) / 64) * 64)
             return set_error("vk_gemm_grouped: K=%d needs lda padded to a multiple of 64", q.K);
         if (layout != VK_TN && q.bias_grad) return set_error("vk_gemm_grouped: bias_grad is a TN (wgrad) feature");
@@ -275,7 +279,7 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
         k.A = (const char*)q.A; k.B = (const char*)q.B; k.C = (char*)q.C; k.C2 = (char*)q.C2; k.bias = q.bias;
         k.R = (const char*)q.R; k.bias_grad = q.bias_grad; k.dyn = q.dyn;
         k.M = q.M; k.N = q.N; k.K = q.K; k.lda = q.lda; k.ldb = q.ldb; k.ldc = q.ldc; k.ldr = q.ldr; k.n_store = q.n_store;
-        const int ncols = (epilogue == VK_EPI_F32 && q.n_store > q.N) ? q.n_store : q.N;
+        const int ncols = ((epilogue == VK_EPI_F32 || epilogue == VK_EPI_F32_ACC) && q.n_store > q.N) ? q.n_store : q.N;
         k.tiles_n = (ncols + BN - 1) / BN;
         k.tile_start = total;
         total += ((q.M + BM - 1) / BM) * k.tiles_n;

@@ -14,6 +14,15 @@ constexpr float LN_EPS = 1e-12f;
 constexpr int LN_THREADS = 256;
 constexpr int LN_BWD_ROWS = 32;     // rows per workgroup in the backward (8 per wave)
 
+// Philox row of `row` under the two-segment mapping of vk_ln_args.seg (see include/volta_hip.h)
+__device__ __forceinline__ uint32_t drop_row(const vk_drop_rows (&seg)[2], int split, int row, uint32_t& site) {
+    const int si = row >= split ? 1 : 0;
+    const int r = si ? row - split : row;
+    site = seg[si].site;
+    if (seg[si].div <= 0) return (uint32_t)r;
+    return (uint32_t)((r / seg[si].div) * seg[si].mul + (r % seg[si].div) + seg[si].off);
+}
+
 __device__ __forceinline__ void load4(const uint16_t* p, float (&v)[4]) {
     u32x2 r = *(const u32x2*)p;
     v[0] = bf2f(r[0] & 0xFFFF); v[1] = bf2f(r[0] >> 16); v[2] = bf2f(r[1] & 0xFFFF); v[3] = bf2f(r[1] >> 16);
@@ -26,14 +35,15 @@ template <int NCH>
 __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(vk_ln_args a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row = blockIdx.x * 4 + wave;
-    if (row >= a.M) return;
+    const int Mrows = a.dyn ? min(*a.dyn, a.M) : a.M;
+    if (row >= Mrows) return;
     const int H = a.H;
     const bool drop_on = a.drop.threshold != 0;
     const uint64_t seed = drop_on ? *a.drop.seed : 0;
-    const uint32_t drow = row < a.split_row ? row : row - a.split_row;
-    vk_dropout dc = a.drop;
-    if (row >= a.split_row) dc.site += 1;
-    DropCfg dcfg{dc.seed, dc.site, dc.threshold, dc.scale};
+    const vk_dropout dc = a.drop;
+    uint32_t dsite;
+    const uint32_t drow = drop_row(a.seg, a.split_row, row, dsite);
+    DropCfg dcfg{dc.seed, dsite, dc.threshold, dc.scale};
     const uint16_t* d = (const uint16_t*)a.d + (size_t)row * H;
     const uint16_t* x = a.x ? (const uint16_t*)a.x + (size_t)row * H : nullptr;
 
@@ -55,6 +65,11 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(vk_ln_args a) {
                 load4(x + c, xv);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) z[j][r] += xv[r];
+            }
+            if (a.addvec) {
+                const f32x4 av = *(const f32x4*)(a.addvec + c);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) z[j][r] += av[r];
             }
             sum += z[j][0] + z[j][1] + z[j][2] + z[j][3];
         }
@@ -109,11 +124,13 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(vk_ln_bwd_args a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) pg[j][r] = pb[j][r] = 0.f;
 
+    const int Mrows = a.dyn ? min(*a.dyn, a.M) : a.M;
     for (int it = 0; it < LN_BWD_ROWS / 4; ++it) {
         const int row = blockIdx.x * LN_BWD_ROWS + it * 4 + wave;
-        if (row >= a.M) break;
-        const uint32_t drow = row < a.split_row ? row : row - a.split_row;
-        DropCfg dcfg{a.drop.seed, a.drop.site + (row >= a.split_row ? 1u : 0u), a.drop.threshold, a.drop.scale};
+        if (row >= Mrows) break;
+        uint32_t dsite;
+        const uint32_t drow = drop_row(a.seg, a.split_row, row, dsite);
+        DropCfg dcfg{a.drop.seed, dsite, a.drop.threshold, a.drop.scale};
         const uint16_t* dy = (const uint16_t*)a.dy + (size_t)row * H;
         const uint16_t* z = (const uint16_t*)a.z + (size_t)row * H;
         const float mean = a.mean[row], rstd = a.rstd[row];
@@ -184,12 +201,13 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(vk_ln_bwd_args a) {
     }
 }
 
-__global__ void ln_bwd_finalize_kernel(const float* partial, int nblk, int H, float* dgamma, float* dbeta) {
+__global__ void ln_bwd_finalize_kernel(const float* partial, int nblk, int H, float* dgamma, float* dbeta, int accumulate) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 2 * H) return;
     float s = 0.f;
     for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * 2 * H + i];
-    if (i < H) dgamma[i] = s; else dbeta[i - H] = s;
+    float* o = i < H ? dgamma + i : dbeta + (i - H);
+    *o = accumulate ? *o + s : s;
 }
 
 }  // namespace vk
@@ -228,6 +246,6 @@ extern "C" int vk_ln_bwd(const vk_ln_bwd_args* a, vk_stream_t stream) {
         default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, *a); break;
     }
     hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * a->H + 255) / 256), dim3(256), 0, s, a->partial, nblk, a->H,
-                       a->dgamma, a->dbeta);
+                       a->dgamma, a->dbeta, a->accumulate);
     return check_launch("vk_ln_bwd");
 }

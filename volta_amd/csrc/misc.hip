@@ -17,7 +17,30 @@ __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, uint16_t* __
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[n8 * 8 + threadIdx.x] = f2bf(src[n8 * 8 + threadIdx.x]);
 }
 
+// out = a * b over rows * row_len bf16 elements (8 per lane)
+__global__ void mul_bf16_kernel(const uint16_t* a, const uint16_t* b, uint16_t* out, size_t n, const int32_t* dyn_rows, int row_len) {
+    if (dyn_rows) { const size_t lim = (size_t)(*dyn_rows) * row_len; if (lim < n) n = lim; }
+    const size_t n8 = n >> 3;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const u32x4 x = *(const u32x4*)(a + i * 8), y = *(const u32x4*)(b + i * 8);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = pack2bf(bf2f(x[k] & 0xFFFF) * bf2f(y[k] & 0xFFFF), bf2f(x[k] >> 16) * bf2f(y[k] >> 16));
+        *(u32x4*)(out + i * 8) = o;
+    }
+}
+
 }  // namespace vk
+
+extern "C" int vk_mul_bf16(const void* a, const void* b, void* out, int64_t n, const int32_t* dyn_rows, int row_len, vk_stream_t s) {
+    if (n <= 0) return 0;
+    if (n % 8 || row_len % 8) return vk::set_error("vk_mul_bf16: n and row_len must be multiples of 8");
+    int64_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(vk::mul_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const uint16_t*)a, (const uint16_t*)b,
+                       (uint16_t*)out, (size_t)n, dyn_rows, row_len);
+    return vk::check_launch("vk_mul_bf16");
+}
 
 extern "C" int vk_set_seed(uint64_t* seed_dev, uint64_t seed, vk_stream_t s) {
     hipLaunchKernelGGL(vk::set_seed_kernel, dim3(1), dim3(1), 0, (hipStream_t)s, seed_dev, seed);

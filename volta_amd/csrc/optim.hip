@@ -1,0 +1,110 @@
+// Optimizer-side kernels over the flat fp32 parameter / gradient arenas (HBM-bound, 16-byte accesses):
+//   * global gradient L2 norm + clip coefficient (torch.nn.utils.clip_grad_norm_, train_concap.py:307-308),
+//     left on the device: no host sync
+//   * fused multi-tensor AdamW with pytorch-transformers 1.1.0 semantics (train_concap.py:227,310): decay
+//     applied AFTER the Adam update with the un-corrected lr, eps added to sqrt(v) before bias correction.
+//     One launch for all tensors (the reference steps 508 parameter groups from Python); also refreshes
+//     the bf16 shadow copy of the weights used by the MFMA GEMMs.  Replaces nothing in apex that volta
+//     calls (apex/csrc/multi_tensor_adam.cu is the closest relative, with different arithmetic).
+#include "common.h"
+#include "../../include/volta_hip.h"
+#include "util.h"
+
+namespace vk {
+
+constexpr int NORM_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* g, size_t n4, float* partial) {
+    __shared__ float sh[4];
+    float s = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const f32x4 v = *(const f32x4*)(g + i * 4);
+        s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+// out[0] = ||g * pre_scale||, out[1] = clip coefficient (multiplies the gradients in the optimizer)
+__global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* partial, int nblk, float pre_scale, float max_norm, float* out) {
+    __shared__ double sh[4];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nblk; i += 256) s += (double)partial[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float norm = (float)sqrt(sh[0] + sh[1] + sh[2] + sh[3]) * pre_scale;
+        out[0] = norm;
+        float coef = 1.f;
+        if (max_norm > 0.f) { coef = max_norm / (norm + 1e-6f); if (coef > 1.f) coef = 1.f; }
+        out[1] = coef;
+    }
+}
+
+__global__ __launch_bounds__(256) void adamw_kernel(vk_adamw_args a) {
+    const size_t chunk = blockIdx.x;
+    const int cls = a.chunk_class ? a.chunk_class[chunk] : 0;
+    const float lr = a.lr * a.cls_lr_mult[cls], wd = a.cls_wd[cls];
+    const float gs = a.grad_scale * (a.clip ? a.clip[1] : 1.f);
+    const size_t i = chunk * 1024 + threadIdx.x * 4;
+    const f32x4 g = *(const f32x4*)(a.g + i);
+    f32x4 p = *(f32x4*)(a.p + i), m = *(f32x4*)(a.m + i), v = *(f32x4*)(a.v + i);
+    const float step = lr * a.step_mult;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float gr = g[r] * gs;
+        m[r] = a.beta1 * m[r] + (1.f - a.beta1) * gr;
+        v[r] = a.beta2 * v[r] + (1.f - a.beta2) * gr * gr;
+        p[r] = p[r] - step * (m[r] / (sqrtf(v[r]) + a.eps));
+        if (wd > 0.f) p[r] = p[r] - lr * wd * p[r];
+    }
+    *(f32x4*)(a.p + i) = p; *(f32x4*)(a.m + i) = m; *(f32x4*)(a.v + i) = v;
+    if (a.shadow) *(u32x2*)((uint16_t*)a.shadow + i) = u32x2{pack2bf(p[0], p[1]), pack2bf(p[2], p[3])};
+}
+
+__global__ __launch_bounds__(256) void axpy_kernel(float* y, const float* x, float alpha, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 a = *(f32x4*)(y + i * 4);
+        const f32x4 b = *(const f32x4*)(x + i * 4);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a[r] += alpha * b[r];
+        *(f32x4*)(y + i * 4) = a;
+    }
+}
+
+}  // namespace vk
+
+using namespace vk;
+
+extern "C" int vk_grad_norm_workspace_floats(void) { return NORM_BLOCKS; }
+
+extern "C" int vk_grad_norm_clip(const float* g, int64_t n, float pre_scale, float max_norm, float* partial, float* out, vk_stream_t s) {
+    if (n % 4 || ((uintptr_t)g & 15)) return set_error("vk_grad_norm_clip: n %% 4 == 0 and 16-byte alignment required");
+    hipStream_t st = (hipStream_t)s;
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, st, g, (size_t)(n / 4), partial);
+    hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, partial, NORM_BLOCKS, pre_scale, max_norm, out);
+    return check_launch("vk_grad_norm_clip");
+}
+
+extern "C" int vk_adamw_step(const vk_adamw_args* a, vk_stream_t s) {
+    if (a->n % 1024) return set_error("vk_adamw_step: arena length must be a multiple of 1024 elements");
+    if (a->n == 0) return 0;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(a->n / 1024)), dim3(256), 0, (hipStream_t)s, *a);
+    return check_launch("vk_adamw_step");
+}
+
+extern "C" int vk_axpy_f32(float* y, const float* x, float alpha, int64_t n, vk_stream_t s) {
+    if (n % 4) return set_error("vk_axpy_f32: n %% 4 != 0");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(axpy_kernel, dim3(2048), dim3(256), 0, (hipStream_t)s, y, x, alpha, (size_t)(n / 4));
+    return check_launch("vk_axpy_f32");
+}
+
+extern "C" int vk_memset_async(void* p, int value, int64_t bytes, vk_stream_t s) {
+    if (bytes <= 0) return 0;
+    hipError_t e = hipMemsetAsync(p, value, (size_t)bytes, (hipStream_t)s);
+    if (e != hipSuccess) return set_error("vk_memset_async: %s", hipGetErrorString(e));
+    return 0;
+}

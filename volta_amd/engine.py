@@ -1,0 +1,813 @@
+"""Host side of the MI355X engine: flat parameter arenas and the static execution plan.
+
+Design: for a given (batch, text length, region count) every activation, weight and gradient
+buffer is fixed, so a pre-training step is compiled ONCE into two command lists (forward, backward) of
+pre-bound kernel launches (`vk_op`, include/volta_hip.h) that the C++ executor replays each step.  No
+autograd graph, no per-op Python: `BertForVLPreTraining.forward` costs one C call, `backward` another.
+
+Parameters live in one flat fp32 arena (each nn.Parameter is a view of it), mirrored by a bf16 shadow
+arena (MFMA operands), a fp32 gradient arena (wgrad GEMMs write straight into it; DDP buckets are ranges
+of it) and, in the optimizer, two moment arenas.  Q/K/V weights of a sub-layer are adjacent, so the three
+projections run as one [3H, H] GEMM.
+
+Dropout sites are numbered in the order of the reference's forward (embeddings; per sub-layer: tt, tv,
+vv, vt probabilities, text output, vision output; pooled) -- the contract the mask-replay tests rely on.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+from ._lib import check, ptr
+from .modules import sublayer_schedule
+
+CHUNK = 1024
+NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")
+
+
+def _round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+# ======================================================================================== arenas
+class ParamArena:
+    """Flat master / shadow / gradient storage; re-points every Parameter at its slice."""
+
+    def __init__(self, model, device):
+        named = list(model.named_parameters())
+        byname = dict(named)
+        slots, seen = [], set()
+        for name, p in named:
+            if name in seen:
+                continue
+            group = [name]
+            for q in ("query", "v_query"):
+                tag = ".attention_self.%s." % q
+                if tag in name:
+                    pre, suf = name.split(tag)
+                    kq = q.replace("query", "")
+                    group = ["%s.attention_self.%s%s.%s" % (pre, kq, k, suf) for k in ("query", "key", "value")]
+            assert all(g in byname for g in group), group
+            seen.update(group)
+            slots.append(group)
+        self.offset, self.shape = {}, {}
+        classes = []
+        off = 0
+        for group in slots:
+            start = off
+            for g in group:
+                self.offset[g] = off
+                self.shape[g] = tuple(byname[g].shape)
+                off += byname[g].numel()
+            off = _round_up(off, CHUNK)
+            nd = any(k in group[0] for k in NO_DECAY)
+            assert all(any(k in g for k in NO_DECAY) == nd for g in group)
+            classes += [1 if nd else 0] * ((off - start) // CHUNK)
+        self.total = off
+        self.device = device
+        self.master = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.shadow = torch.zeros(self.total, dtype=torch.bfloat16, device=device)
+        self.grad = torch.zeros(self.total, dtype=torch.float32, device=device)
+        self.chunk_class = torch.tensor(classes, dtype=torch.uint8, device=device)
+        self.names = [n for n, _ in named]
+        self.params = byname
+        with torch.no_grad():
+            for name, p in named:
+                v = self.view(name)
+                v.copy_(p.data.to(device=device, dtype=torch.float32))
+                p.data = v
+                p.grad = None
+        self.shadow_version = -1
+
+    def view(self, name, which="master"):
+        buf = getattr(self, which)
+        o = self.offset[name]
+        n = 1
+        for d in self.shape[name]:
+            n *= d
+        return buf[o:o + n].view(self.shape[name])
+
+    def span(self, names, which, shape):
+        """Contiguous view over consecutive tensors of one slot (the fused Q|K|V block)."""
+        buf = getattr(self, which)
+        o = self.offset[names[0]]
+        n = 1
+        for d in shape:
+            n *= d
+        for a, b in zip(names[:-1], names[1:]):
+            assert self.offset[b] == self.offset[a] + int(torch.tensor(self.shape[a]).prod())
+        return buf[o:o + n].view(shape)
+
+    def intact(self):
+        return all(p.data_ptr() == self.master.data_ptr() + 4 * self.offset[n] for n, p in self.params.items())
+
+    def refresh_shadow(self, force=False):
+        """bf16 copies of the weights; skipped when nothing wrote the master arena through torch since the
+        last refresh (the fused AdamW refreshes the shadow itself and does not bump the version)."""
+        v = self.master._version
+        if force or v != self.shadow_version:
+            check(L.lib.vk_cast_f32_bf16(ptr(self.master), ptr(self.shadow), self.total, L.stream_ptr()))
+            self.shadow_version = v
+
+
+# ======================================================================================== plan
+class Plan:
+    def __init__(self):
+        self.ops, self.keep = [], []
+        self.c_ops = None
+        self.timing = None
+
+    def add(self, kind, a, i0=0, i1=0, i2=0, b=None, c=None):
+        self.ops.append((kind, i0, i1, i2, a, b, c))
+
+    def freeze(self):
+        arr = (L.Op * max(1, len(self.ops)))()
+        for i, (kind, i0, i1, i2, a, b, c) in enumerate(self.ops):
+            arr[i] = L.Op(kind, i0, i1, i2, _addr(a), _addr(b), _addr(c))
+        self.c_ops = arr
+        return self
+
+    def run(self, start=0, end=None):
+        end = len(self.ops) if end is None else end
+        if end > start:
+            base = C.cast(C.byref(self.c_ops, start * C.sizeof(L.Op)), C.POINTER(L.Op))
+            if self.timing is not None:
+                ms = C.cast(C.byref(self.timing, start * C.sizeof(C.c_float)), C.POINTER(C.c_float))
+                check(L.lib.vk_run_ops_timed(base, end - start, L.stream_ptr(), ms))
+            else:
+                check(L.lib.vk_run_ops(base, end - start, L.stream_ptr()))
+
+    def enable_timing(self, on=True):
+        """Per-op HIP-event timing (synchronises the stream on every run; profiling passes only)."""
+        self.timing = (C.c_float * max(1, len(self.ops)))() if on else None
+
+
+def _addr(o):
+    if o is None:
+        return None
+    if isinstance(o, int):
+        return o
+    if isinstance(o, torch.Tensor):
+        return o.data_ptr()
+    return C.addressof(o)
+
+
+class Stream:
+    """Per-modality geometry: 0 = text, 1 = vision."""
+
+    def __init__(self, L_, B, H):
+        self.L, self.M, self.H = L_, B * L_, H
+
+
+class StepEngine:
+    """Buffers + forward / backward command lists of one (B, T, Rv, train) shape."""
+
+    def __init__(self, cfg, arena, B, T, Rv, train):
+        self.cfg, self.arena, self.B, self.T, self.Rv, self.train = cfg, arena, B, T, Rv, train
+        dev = arena.device
+        self.dev = dev
+        H, Hv = cfg.hidden_size, cfg.v_hidden_size
+        if H != Hv or H % 256 or H // cfg.num_attention_heads != 64 or cfg.num_attention_heads != cfg.v_num_attention_heads:
+            raise NotImplementedError("the HIP engine covers the ctrl_* geometry: hidden == v_hidden, multiple of 256, "
+                                      "head size 64 (got %d / %d, %d heads)" % (H, Hv, cfg.num_attention_heads))
+        if cfg.sublayer2attn_hidden_size or cfg.sublayer2num_attention_heads or cfg.sublayer2intermediate_size or \
+                cfg.sublayer2v_attn_hidden_size or cfg.sublayer2v_num_attention_heads or cfg.sublayer2v_intermediate_size:
+            raise NotImplementedError("per-sub-layer sizes (non-ctrl configs) are out of scope (SURVEY.md 8f-4)")
+        if cfg.hidden_act != "gelu" or cfg.v_hidden_act != "gelu" or cfg.fusion_method != "mul":
+            raise NotImplementedError("engine supports gelu activations and 'mul' fusion (all ctrl_* configs)")
+        if [k for k, w in cfg.visual_target_weights.items() if w > 0] != ["0"]:
+            raise NotImplementedError("only visual target '0' (kl_1601) is on the hot path (SURVEY.md 2.1 #4)")
+        if T > 64 or Rv > 128:
+            raise NotImplementedError("sequence lengths above (64, 128) exceed the attention tile budget")
+        self.H, self.I, self.nh = H, cfg.intermediate_size, cfg.num_attention_heads
+        self.st = [Stream(T, B, H), Stream(Rv, B, H)]
+        self.R = Rv - (1 if cfg.add_global_imgfeat is not None else 0)
+        self.bufs = {}
+        self.keep = []
+        self.fwd, self.bwd = Plan(), Plan()
+        self.bwd_groups = []          # per forward stage: list of op tuples, replayed in reverse stage order
+        self.site = 0
+        self.seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.inputs = {}              # name -> list of (struct, field) patched every step
+        self.taps = {}
+        self._build()
+
+    # ---------------------------------------------------------------- helpers
+    def buf(self, name, shape, dtype=torch.bfloat16, zero=False):
+        assert name not in self.bufs, name
+        t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.dev)
+        self.bufs[name] = t
+        return t
+
+    def tmp(self, name, shape, dtype=torch.bfloat16):
+        """Backward temporaries are shared by all sub-layers."""
+        if name not in self.bufs:
+            self.bufs[name] = torch.empty(shape, dtype=dtype, device=self.dev)
+        t = self.bufs[name]
+        assert tuple(t.shape) == tuple(shape) and t.dtype == dtype, (name, t.shape, shape)
+        return t
+
+    def drop(self, p):
+        site = self.site
+        self.site += 1
+        return L.dropout_cfg(self.seed.data_ptr(), site, p if self.train else 0.0)
+
+    def k(self, obj):
+        self.keep.append(obj)
+        return obj
+
+    def patch(self, name, struct, field, index=None):
+        self.inputs.setdefault(name, []).append((struct, field, index))
+
+    def W(self, name):
+        return self.arena.view(name, "shadow")
+
+    def Pm(self, name):
+        return self.arena.view(name, "master")
+
+    def G(self, name):
+        return self.arena.view(name, "grad")
+
+    def gemm(self, plan_ops, layout, epi, probs):
+        arr = self.k((L.GemmProblem * len(probs))(*probs))
+        plan_ops.append((L.OP_GEMM, layout, epi, len(probs), arr, None, None))
+
+    def prob(self, A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, C2=None, bias_grad=None, dyn=None, n_store=0):
+        return L.GemmProblem(_addr(A), _addr(B), _addr(Cout), _addr(C2), _addr(bias), _addr(R), _addr(bias_grad), _addr(dyn),
+                             M, N, K, lda, ldb, ldc, ldr, n_store)
+
+    def generic(self, fn, p=(), n=(), f=(), drop=None):
+        g = L.GenericArgs()
+        g.fn = fn
+        for i, x in enumerate(p):
+            g.p[i] = _addr(x)
+        for i, x in enumerate(n):
+            g.n[i] = int(x)
+        for i, x in enumerate(f):
+            g.f[i] = float(x)
+        g.drop = drop or L.dropout_cfg(None, 0, 0.0)
+        return self.k(g)
+
+    def ln_args(self, d, x, gname, bname, y, z, mean, rstd, M, drop, post=0, out_scale=1.0, addvec=None, dyn=None, segs=None):
+        a = L.LnArgs(_addr(d), _addr(x), _addr(addvec), _addr(self.Pm(gname)), _addr(self.Pm(bname)), _addr(y), _addr(z), _addr(mean),
+                     _addr(rstd), _addr(dyn), M, self.H, M, post, out_scale, drop, _mk_segs(drop, segs))
+        return self.k(a)
+
+    def ln_bwd_args(self, dy, z, mean, rstd, gname, bname, dz, dd, M, drop, post=0, out_scale=1.0, dyn=None, segs=None, accumulate=0):
+        partial = self.tmp("ln_partial", (L.lib.vk_ln_bwd_partial_rows(max(self.st[0].M, self.st[1].M)) * 2 * self.H,), torch.float32)
+        a = L.LnBwdArgs(_addr(dy), _addr(z), _addr(mean), _addr(rstd), _addr(self.Pm(gname)), _addr(dz), _addr(dd), _addr(partial),
+                        _addr(self.G(gname)), _addr(self.G(bname)), _addr(dyn), M, self.H, M, post, out_scale, accumulate, drop,
+                        _mk_segs(drop, segs))
+        return self.k(a)
+
+    # ---------------------------------------------------------------- build
+    def _build(self):
+        cfg, B, H = self.cfg, self.B, self.H
+        st = self.st
+        f = self.fwd.ops
+        # per-step inputs (static staging copies are avoided: the few ops that read them are patched)
+        self.masks = [self.buf("mask_t", (B, self.T), torch.float32), self.buf("mask_v", (B, self.Rv), torch.float32)]
+        for m, name in ((0, "attention_mask"), (1, "image_attention_mask")):
+            g = self.generic(L.FN_MASK_PREP, p=(None, self.masks[m]), n=(B * st[m].L,))
+            self.patch(name, g, "p", 0)
+            f.append((L.OP_GENERIC, 0, 0, 0, g, None, None))
+        self.x = [None, None]        # current hidden state buffers
+        self.level = [0, 0]          # number of sub-layers that transformed x[m] so far (ping-pong parity of dX)
+        self.bwd_pro = []            # zero-fills of gradient tensors that are accumulated with atomics
+        kind = cfg.image_embeddings
+        bwd_stages = []
+        nemb = 1 if kind == "visualbert" else 2
+        self.stage_prefix = [["bert.embeddings.", "bert.v_embeddings."]] * nemb + [["bert.encoder.layer.%d." % n] for n, _ in sublayer_schedule(cfg)]
+        if kind == "vilbert":
+            bwd_stages.append(self._emb_text("bert.embeddings."))
+            bwd_stages.append(self._emb_image_vilbert("bert.v_embeddings."))
+        elif kind == "lxmert":
+            bwd_stages.append(self._emb_text("bert.embeddings."))
+            bwd_stages.append(self._emb_image_lxmert("bert.v_embeddings."))
+        elif kind == "uniter":
+            bwd_stages.append(self._emb_text("bert.embeddings."))
+            bwd_stages.append(self._emb_image_uniter("bert.embeddings."))
+        elif kind == "visualbert":
+            bwd_stages.append(self._emb_visualbert("bert.embeddings."))
+        else:
+            raise NotImplementedError("image_embeddings=%r: VL-BERT's embedding path is not built yet (DESIGN.md, scope)" % kind)
+        self.taps["emb_t"], self.taps["emb_v"] = self.x[0], self.x[1]
+        for n, typ in sublayer_schedule(cfg):
+            bwd_stages.append(self._attn_sublayer(n) if typ == "attn" else self._ffn_sublayer(n))
+            self.taps["t%d" % n], self.taps["v%d" % n] = self.x[0], self.x[1]
+        head_bwd = self._heads()
+        # backward list: zero-fills, heads, then stages in reverse; bwd_marks[s] = op index at which backward
+        # stage s is complete (stage 0 = heads), param_ready_stage[name] = stage after which its gradient is final
+        self.bwd.ops = list(self.bwd_pro) + list(head_bwd)
+        self.bwd_marks = [len(self.bwd.ops)]
+        for ops in reversed(bwd_stages):
+            self.bwd.ops += ops
+            self.bwd_marks.append(len(self.bwd.ops))
+        prefixes = [["bert.t_pooler.", "bert.v_pooler.", "cls."]] + [pf for pf in reversed(self.stage_prefix)]
+        self.param_ready_stage = {}
+        for name in self.arena.params:
+            self.param_ready_stage[name] = max(i for i, pf in enumerate(prefixes) if any(name.startswith(q) for q in pf))
+        self.fwd.freeze()
+        self.bwd.freeze()
+
+    # -- gradient buffers of the hidden states.  dX[m] ping-pongs between two buffers: the k-th sub-layer (in
+    # forward order) that transforms x[m] reads d(loss)/d(its output) from buffer k%2 and writes the gradient of
+    # its input to buffer (k-1)%2; the embeddings read buffer 0, the heads fill buffer (final k)%2.
+    def _dx(self, m, parity):
+        return self.tmp("dx%d_%d" % (m, parity), (self.st[m].M, self.H))
+
+    def _dx_step(self, m):
+        self.level[m] += 1
+        k = self.level[m]
+        return self._dx(m, k % 2), self._dx(m, (k - 1) % 2)
+
+    def _zero_grad(self, t):
+        self.bwd_pro.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MEMSET, p=(t,), n=(t.numel() * t.element_size(), 0)), None, None))
+
+    # ---------------------------------------------------------------- embeddings
+    def _emb_text(self, pre):
+        cfg, st, H = self.cfg, self.st[0], self.H
+        f = self.fwd.ops
+        z = self.buf("emb_t_z", (st.M, H))
+        y = self.buf("emb_t_y", (st.M, H))
+        mean, rstd = self.buf("emb_t_mean", (st.M,), torch.float32), self.buf("emb_t_rstd", (st.M,), torch.float32)
+        ea = self.k(L.EmbedArgs(None, None, None, _addr(self.Pm(pre + "word_embeddings.weight")), _addr(self.Pm(pre + "position_embeddings.weight")),
+                                _addr(self.Pm(pre + "token_type_embeddings.weight")), None, _addr(z), st.M, st.L, H,
+                                cfg.vocab_size, cfg.max_position_embeddings, cfg.type_vocab_size))
+        self.patch("input_ids", ea, "ids")
+        self.patch("token_type_ids", ea, "type_ids")
+        f.append((L.OP_EMBED_FWD, 0, 0, 0, ea, None, None))
+        dr = self.drop(cfg.hidden_dropout_prob)
+        f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(z, None, pre + "LayerNorm.weight", pre + "LayerNorm.bias", y, None, mean, rstd, st.M, dr, post=1), None, None))
+        self.x[0] = y
+        # backward
+        b = []
+        dz = self.tmp("dz0", (st.M, H))
+        b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(self._dx(0, 0), z, mean, rstd, pre + "LayerNorm.weight", pre + "LayerNorm.bias", dz, None, st.M, dr, post=1), None, None))
+        gpos, gtyp = self.G(pre + "position_embeddings.weight"), self.G(pre + "token_type_embeddings.weight")
+        self._zero_grad(gpos)
+        self._zero_grad(gtyp)
+        eb = self.k(L.EmbedBwdArgs(_addr(dz), None, None, None, _addr(self.G(pre + "word_embeddings.weight")), _addr(gpos), _addr(gtyp),
+                                   st.M, st.L, H, cfg.type_vocab_size, cfg.vocab_size, cfg.max_position_embeddings))
+        self.patch("input_ids", eb, "ids")
+        self.patch("token_type_ids", eb, "type_ids")
+        b.append((L.OP_EMBED_BWD, 0, 0, 0, eb, None, None))
+        return b
+
+    def _img_proj(self, pre, wname, tag):
+        """feat (fp32) -> bf16 -> [Mv, H] = feat W^T + b ; returns (proj, feat_bf16)."""
+        cfg, st, H = self.cfg, self.st[1], self.H
+        f = self.fwd.ops
+        F_ = cfg.v_feature_size
+        if F_ % 64:
+            raise NotImplementedError("v_feature_size must be a multiple of 64")
+        featb = self.buf(tag + "_feat_bf16", (st.M, F_))
+        g = self.generic(L.FN_CAST, p=(None, featb), n=(st.M * F_,))
+        self.patch("image_feat", g, "p", 0)
+        f.append((L.OP_GENERIC, 0, 0, 0, g, None, None))
+        proj = self.buf(tag + "_proj", (st.M, H))
+        self.gemm(f, L.NT, L.EPI_BF16, [self.prob(featb, self.W(pre + wname + ".weight"), proj, st.M, H, F_, F_, F_, H, bias=self.Pm(pre + wname + ".bias"))])
+        return proj, featb
+
+    def _loc_proj(self, pre, tag):
+        cfg, st, H = self.cfg, self.st[1], self.H
+        out = self.buf(tag + "_locproj", (st.M, H))
+        g = self.generic(L.FN_LOC_FWD, p=(None, self.Pm(pre + "image_location_embeddings.weight"), self.Pm(pre + "image_location_embeddings.bias"), out),
+                         n=(st.M, H, cfg.num_locs))
+        self.patch("image_loc", g, "p", 0)
+        self.fwd.ops.append((L.OP_GENERIC, 0, 0, 0, g, None, None))
+        return out
+
+    def _img_proj_bwd(self, b, pre, wname, dz, featb):
+        st, H, F_ = self.st[1], self.H, self.cfg.v_feature_size
+        self.gemm(b, L.TN, L.EPI_F32, [self.prob(dz, featb, self.G(pre + wname + ".weight"), H, F_, st.M, H, F_, F_, bias_grad=self.G(pre + wname + ".bias"))])
+
+    def _loc_proj_bwd(self, b, pre, dz):
+        st, H = self.st[1], self.H
+        part = self.tmp("loc_partial", (L.lib.vk_rows32(st.M) * 9 * H,), torch.float32)
+        g = self.generic(L.FN_LOC_BWD, p=(dz, None, part, self.G(pre + "image_location_embeddings.weight"), self.G(pre + "image_location_embeddings.bias")),
+                         n=(st.M, H, self.cfg.num_locs))
+        self.patch("image_loc", g, "p", 1)
+        b.append((L.OP_GENERIC, 0, 0, 0, g, None, None))
+
+    def _emb_image_vilbert(self, pre):
+        cfg, st, H = self.cfg, self.st[1], self.H
+        proj, featb = self._img_proj(pre, "image_embeddings", "emb_v")
+        loc = self._loc_proj(pre, "emb_v")
+        y = self.buf("emb_v_y", (st.M, H))
+        mean, rstd = self.buf("emb_v_mean", (st.M,), torch.float32), self.buf("emb_v_rstd", (st.M,), torch.float32)
+        dr = self.drop(cfg.v_hidden_dropout_prob)
+        self.fwd.ops.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(proj, loc, pre + "LayerNorm.weight", pre + "LayerNorm.bias", y, proj, mean, rstd, st.M, dr, post=1), None, None))
+        self.x[1] = y
+        b = []
+        dz = self.tmp("dz1", (st.M, H))
+        b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(self._dx(1, 0), proj, mean, rstd, pre + "LayerNorm.weight", pre + "LayerNorm.bias", dz, None, st.M, dr, post=1), None, None))
+        self._img_proj_bwd(b, pre, "image_embeddings", dz, featb)
+        self._loc_proj_bwd(b, pre, dz)
+        return b
+
+    def _emb_image_lxmert(self, pre):
+        cfg, st, H = self.cfg, self.st[1], self.H
+        f = self.fwd.ops
+        proj, featb = self._img_proj(pre, "image_embeddings", "emb_v")
+        loc = self._loc_proj(pre, "emb_v")
+        nodrop = L.dropout_cfg(None, 0, 0.0)
+        a_n, b_n = self.buf("emb_v_imgn", (st.M, H)), self.buf("emb_v_locn", (st.M, H))
+        st_a = [self.buf("emb_v_%s" % s, (st.M,), torch.float32) for s in ("mean_a", "rstd_a", "mean_b", "rstd_b")]
+        f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(proj, None, pre + "ImgLayerNorm.weight", pre + "ImgLayerNorm.bias", a_n, None, st_a[0], st_a[1], st.M, nodrop), None, None))
+        f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(loc, None, pre + "LocLayerNorm.weight", pre + "LocLayerNorm.bias", b_n, None, st_a[2], st_a[3], st.M, nodrop), None, None))
+        y = self.buf("emb_v_y", (st.M, H))
+        dr = self.drop(cfg.v_hidden_dropout_prob)
+        f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ADD_DROPOUT, p=(a_n, b_n, y), n=(st.M, H, 0), f=(0.5,), drop=dr), None, None))
+        self.x[1] = y
+        b = []
+        g = self.tmp("dz1", (st.M, H))
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ADD_DROPOUT, p=(self._dx(1, 0), None, g), n=(st.M, H, 1), f=(0.5,), drop=dr), None, None))
+        dza, dzb = self.tmp("dd1", (st.M, H)), self.tmp("dctx1", (st.M, H))
+        b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(g, proj, st_a[0], st_a[1], pre + "ImgLayerNorm.weight", pre + "ImgLayerNorm.bias", dza, None, st.M, nodrop), None, None))
+        b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(g, loc, st_a[2], st_a[3], pre + "LocLayerNorm.weight", pre + "LocLayerNorm.bias", dzb, None, st.M, nodrop), None, None))
+        self._img_proj_bwd(b, pre, "image_embeddings", dza, featb)
+        self._loc_proj_bwd(b, pre, dzb)
+        return b
+
+    def _emb_image_uniter(self, pre):
+        cfg, st, H = self.cfg, self.st[1], self.H
+        f = self.fwd.ops
+        proj, featb = self._img_proj(pre, "image_embeddings", "emb_v")
+        loc = self._loc_proj(pre, "emb_v")
+        nodrop = L.dropout_cfg(None, 0, 0.0)
+        a_n, b_n = self.buf("emb_v_imgn", (st.M, H)), self.buf("emb_v_locn", (st.M, H))
+        st_a = [self.buf("emb_v_%s" % s, (st.M,), torch.float32) for s in ("mean_a", "rstd_a", "mean_b", "rstd_b", "mean", "rstd")]
+        f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(proj, None, pre + "image_layer_norm.weight", pre + "image_layer_norm.bias", a_n, None, st_a[0], st_a[1], st.M, nodrop), None, None))
+        f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(loc, None, pre + "image_location_layer_norm.weight", pre + "image_location_layer_norm.bias", b_n, None, st_a[2], st_a[3], st.M, nodrop), None, None))
+        y, z = self.buf("emb_v_y", (st.M, H)), self.buf("emb_v_z", (st.M, H))
+        dr = self.drop(cfg.hidden_dropout_prob)
+        type1 = self.Pm(pre + "token_type_embeddings.weight")[1]
+        f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(a_n, b_n, pre + "v_LayerNorm.weight", pre + "v_LayerNorm.bias", y, z, st_a[4], st_a[5], st.M, dr, post=1, addvec=type1), None, None))
+        self.x[1] = y
+        b = []
+        dz = self.tmp("dz1", (st.M, H))
+        b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(self._dx(1, 0), z, st_a[4], st_a[5], pre + "v_LayerNorm.weight", pre + "v_LayerNorm.bias", dz, None, st.M, dr, post=1), None, None))
+        # the broadcast token-type row 1 receives the column sum of dz (the text side zeroed / filled its table first)
+        part = self.tmp("colsum_partial", (L.lib.vk_rows32(st.M) * H,), torch.float32)
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_COLSUM, p=(dz, part, self.G(pre + "token_type_embeddings.weight")[1]), n=(st.M, H, 1)), None, None))
+        dza, dzb = self.tmp("dd1", (st.M, H)), self.tmp("dctx1", (st.M, H))
+        b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dz, proj, st_a[0], st_a[1], pre + "image_layer_norm.weight", pre + "image_layer_norm.bias", dza, None, st.M, nodrop), None, None))
+        b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dz, loc, st_a[2], st_a[3], pre + "image_location_layer_norm.weight", pre + "image_location_layer_norm.bias", dzb, None, st.M, nodrop), None, None))
+        self._img_proj_bwd(b, pre, "image_embeddings", dza, featb)
+        self._loc_proj_bwd(b, pre, dzb)
+        return b
+
+    def _emb_visualbert(self, pre):
+        """One LayerNorm over the per-sample concatenation [text | vision] (embeddings.py:389-392): run as two
+        row kernels sharing gamma/beta; the single dropout site sees rows b*(T+Rv)+t and b*(T+Rv)+T+r."""
+        cfg, H, B = self.cfg, self.H, self.B
+        st_t, st_v = self.st
+        f = self.fwd.ops
+        T, Rv = st_t.L, st_v.L
+        zt = self.buf("emb_t_z", (st_t.M, H))
+        ea = self.k(L.EmbedArgs(None, None, None, _addr(self.Pm(pre + "word_embeddings.weight")), _addr(self.Pm(pre + "position_embeddings.weight")),
+                                _addr(self.Pm(pre + "token_type_embeddings.weight")), None, _addr(zt), st_t.M, T, H,
+                                cfg.vocab_size, cfg.max_position_embeddings, cfg.type_vocab_size))
+        self.patch("input_ids", ea, "ids")
+        self.patch("token_type_ids", ea, "type_ids")
+        f.append((L.OP_EMBED_FWD, 0, 0, 0, ea, None, None))
+        proj, featb = self._img_proj(pre, "projection", "emb_v")
+        # addvec = position_embeddings_visual[0] + token_type_embeddings_visual[1], rebuilt every step (2 tiny ops)
+        vec = self.buf("emb_v_addvec", (H,), torch.float32)
+        self._visualbert_vec = (vec, pre)
+        yt, yv = self.buf("emb_t_y", (st_t.M, H)), self.buf("emb_v_y", (st_v.M, H))
+        zv = self.buf("emb_v_z", (st_v.M, H))
+        stats = [self.buf("emb_%s" % s, (m,), torch.float32) for s, m in (("t_mean", st_t.M), ("t_rstd", st_t.M), ("v_mean", st_v.M), ("v_rstd", st_v.M))]
+        dr = self.drop(cfg.hidden_dropout_prob)
+        seg_t = [(dr.site, T, T + Rv, 0), (dr.site, 0, 0, 0)]
+        seg_v = [(dr.site, Rv, T + Rv, T), (dr.site, 0, 0, 0)]
+        gn, bn = pre + "LayerNorm.weight", pre + "LayerNorm.bias"
+        f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(zt, None, gn, bn, yt, None, stats[0], stats[1], st_t.M, dr, post=1, segs=seg_t), None, None))
+        f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(proj, None, gn, bn, yv, zv, stats[2], stats[3], st_v.M, dr, post=1, addvec=vec, segs=seg_v), None, None))
+        self.x = [yt, yv]
+        b = []
+        dzt, dzv = self.tmp("dz0", (st_t.M, H)), self.tmp("dz1", (st_v.M, H))
+        b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(self._dx(0, 0), zt, stats[0], stats[1], gn, bn, dzt, None, st_t.M, dr, post=1, segs=seg_t), None, None))
+        b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(self._dx(1, 0), zv, stats[2], stats[3], gn, bn, dzv, None, st_v.M, dr, post=1, segs=seg_v, accumulate=1), None, None))
+        for nm in ("position_embeddings.weight", "token_type_embeddings.weight", "position_embeddings_visual.weight", "token_type_embeddings_visual.weight"):
+            self._zero_grad(self.G(pre + nm))
+        part = self.tmp("colsum_partial", (L.lib.vk_rows32(st_v.M) * H,), torch.float32)
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_COLSUM, p=(dzv, part, self.G(pre + "position_embeddings_visual.weight")[0]), n=(st_v.M, H, 0)), None, None))
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_COLSUM, p=(dzv, part, self.G(pre + "token_type_embeddings_visual.weight")[1]), n=(st_v.M, H, 0)), None, None))
+        self._img_proj_bwd(b, pre, "projection", dzv, featb)
+        eb = self.k(L.EmbedBwdArgs(_addr(dzt), None, None, None, _addr(self.G(pre + "word_embeddings.weight")), _addr(self.G(pre + "position_embeddings.weight")),
+                                   _addr(self.G(pre + "token_type_embeddings.weight")), st_t.M, T, H, cfg.type_vocab_size, cfg.vocab_size,
+                                   cfg.max_position_embeddings))
+        self.patch("input_ids", eb, "ids")
+        self.patch("token_type_ids", eb, "type_ids")
+        b.append((L.OP_EMBED_BWD, 0, 0, 0, eb, None, None))
+        return b
+
+    # ---------------------------------------------------------------- encoder sub-layers
+    def _names(self, n, typ):
+        """Parameter names per modality for sub-layer n (shared sub-layers: the text names for both)."""
+        cfg = self.cfg
+        p = "bert.encoder.layer.%d." % n
+        shared = n in cfg.shared_sublayers
+        out = []
+        for m in range(2):
+            v = "v_" if (m == 1 and not shared) else ""
+            if typ == "attn":
+                out.append(dict(q=p + "attention_self.%squery" % v, k=p + "attention_self.%skey" % v, v=p + "attention_self.%svalue" % v,
+                                o=p + "attention_output.%sdense" % v, ln=p + "attention_output.%sLayerNorm" % v))
+            else:
+                out.append(dict(up=p + "intermediate.%sdense" % v, down=p + "output.%sdense" % v, ln=p + "output.%sLayerNorm" % v))
+        return out, shared
+
+    def _attn_sublayer(self, n):
+        cfg, H, B, nh = self.cfg, self.H, self.B, self.nh
+        f = self.fwd.ops
+        gate = [[int(n in cfg.tt_attn_sublayers), int(n in cfg.tv_attn_sublayers)], [int(n in cfg.vt_attn_sublayers), int(n in cfg.vv_attn_sublayers)]]
+        act = [bool(gate[0][0] or gate[0][1]), bool(gate[1][0] or gate[1][1])]
+        names, shared = self._names(n, "attn")
+        ms = [m for m in range(2) if act[m]]
+        tag = "L%d_" % n
+        x_in = list(self.x)
+        qkv = {m: self.buf(tag + "qkv%d" % m, (self.st[m].M, 3 * H)) for m in ms}
+        ctx = {m: self.buf(tag + "ctx%d" % m, (self.st[m].M, H)) for m in ms}
+        lse = {m: self.buf(tag + "lse%d" % m, (B * nh * self.st[m].L,), torch.float32) for m in ms}
+        d = {m: self.buf(tag + "z%d" % m, (self.st[m].M, H)) for m in ms}
+        y = {m: self.buf(tag + "y%d" % m, (self.st[m].M, H)) for m in ms}
+        mean = {m: self.buf(tag + "mean%d" % m, (self.st[m].M,), torch.float32) for m in ms}
+        rstd = {m: self.buf(tag + "rstd%d" % m, (self.st[m].M,), torch.float32) for m in ms}
+
+        def wqkv(m, which):
+            nm = names[m]
+            return self.arena.span([nm["q"] + ".weight", nm["k"] + ".weight", nm["v"] + ".weight"], which, (3 * H, H))
+
+        def bqkv(m, which):
+            nm = names[m]
+            return self.arena.span([nm["q"] + ".bias", nm["k"] + ".bias", nm["v"] + ".bias"], which, (3 * H,))
+
+        self.gemm(f, L.NT, L.EPI_BF16, [self.prob(x_in[m], wqkv(m, "shadow"), qkv[m], self.st[m].M, 3 * H, H, H, H, 3 * H, bias=bqkv(m, "master")) for m in ms])
+        aa = L.AttnArgs()
+        for m in ms:
+            base = qkv[m].data_ptr()
+            aa.q[m], aa.k[m], aa.v[m] = base, base + 2 * H, base + 4 * H
+            aa.ld[m], aa.L[m] = 3 * H, self.st[m].L
+            aa.mask[m] = self.masks[m].data_ptr()
+            aa.ctx[m], aa.ldo[m], aa.lse[m] = ctx[m].data_ptr(), H, lse[m].data_ptr()
+        aa.B, aa.nh, aa.scale = B, nh, 1.0 / math.sqrt(64.0)
+        # dropout sites in the reference's call order: tt, tv, then vv, vt (encoders.py:294-295, 309-310)
+        drops = {}
+        if gate[0][0]:
+            drops[(0, 0)] = self.drop(cfg.attention_probs_dropout_prob)
+        if gate[0][1]:
+            drops[(0, 1)] = self.drop(cfg.attention_probs_dropout_prob)
+        if gate[1][1]:
+            drops[(1, 1)] = self.drop(cfg.v_attention_probs_dropout_prob)
+        if gate[1][0]:
+            drops[(1, 0)] = self.drop(cfg.v_attention_probs_dropout_prob)
+        for i in range(2):
+            for j in range(2):
+                aa.gate[i][j] = gate[i][j]
+                aa.drop[i][j] = drops.get((i, j), L.dropout_cfg(None, 0, 0.0))
+        self.k(aa)
+        f.append((L.OP_ATTN_FWD, 0, 0, 0, aa, None, None))
+        self.gemm(f, L.NT, L.EPI_BF16, [self.prob(ctx[m], self.W(names[m]["o"] + ".weight"), d[m], self.st[m].M, H, H, H, H, H, bias=self.Pm(names[m]["o"] + ".bias")) for m in ms])
+        odrop = {}
+        for m in ms:
+            odrop[m] = self.drop(cfg.hidden_dropout_prob if m == 0 else cfg.v_hidden_dropout_prob)
+            f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(d[m], x_in[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", y[m], d[m], mean[m], rstd[m], self.st[m].M, odrop[m]), None, None))
+            self.x[m] = y[m]
+        # ------------- backward
+        b = []
+        dz, dd, dctx, dqkv, dxn, dxi = {}, {}, {}, {}, {}, {}
+        for i, m in enumerate(ms):
+            dxi[m], dxn[m] = self._dx_step(m)
+            acc = 1 if (shared and i > 0) else 0
+            dz[m] = self.tmp("dz%d" % m, (self.st[m].M, H))
+            dd[m] = self.tmp("dd%d" % m, (self.st[m].M, H)) if self.train else dz[m]
+            b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dxi[m], d[m], mean[m], rstd[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", dz[m],
+                                                              dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc), None, None))
+            dctx[m] = self.tmp("dctx%d" % m, (self.st[m].M, H))
+            dqkv[m] = self.tmp("dqkv%d" % m, (self.st[m].M, 3 * H))
+        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dd[m], self.W(names[m]["o"] + ".weight"), dctx[m], self.st[m].M, H, H, H, H, H) for m in ms])
+        self._wgrad(b, ms, shared, lambda m: (dd[m], ctx[m], self.G(names[m]["o"] + ".weight"), self.G(names[m]["o"] + ".bias"), H, H, H, H))
+        ab = L.AttnBwdArgs()
+        for m in ms:
+            if not (gate[0][m] or gate[1][m]):       # K/V of this modality unused: their gradient is zero
+                b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MEMSET, p=(dqkv[m],), n=(dqkv[m].numel() * 2, 0)), None, None))
+            ab.dctx[m] = dctx[m].data_ptr()
+            base = dqkv[m].data_ptr()
+            ab.dq[m], ab.dk[m], ab.dv[m], ab.ldg[m] = base, base + 2 * H, base + 4 * H, 3 * H
+        self.k(ab)
+        b.append((L.OP_ATTN_BWD, 0, 0, 0, aa, ab, None))
+        self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dqkv[m], wqkv(m, "shadow"), dxn[m], self.st[m].M, H, 3 * H, 3 * H, H, H, R=dz[m], ldr=H) for m in ms])
+        self._wgrad(b, ms, shared, lambda m: (dqkv[m], x_in[m], wqkv(m, "grad"), bqkv(m, "grad"), 3 * H, H, 3 * H, H))
+        return b
+
+    def _ffn_sublayer(self, n):
+        cfg, H, I = self.cfg, self.H, self.I
+        f = self.fwd.ops
+        act = [n in cfg.t_ff_sublayers, n in cfg.v_ff_sublayers]
+        names, shared = self._names(n, "ff")
+        ms = [m for m in range(2) if act[m]]
+        tag = "L%d_" % n
+        x_in = list(self.x)
+        h = {m: self.buf(tag + "h%d" % m, (self.st[m].M, I)) for m in ms}
+        gp = {m: self.buf(tag + "gp%d" % m, (self.st[m].M, I)) for m in ms}
+        d = {m: self.buf(tag + "z%d" % m, (self.st[m].M, H)) for m in ms}
+        y = {m: self.buf(tag + "y%d" % m, (self.st[m].M, H)) for m in ms}
+        mean = {m: self.buf(tag + "mean%d" % m, (self.st[m].M,), torch.float32) for m in ms}
+        rstd = {m: self.buf(tag + "rstd%d" % m, (self.st[m].M,), torch.float32) for m in ms}
+        self.gemm(f, L.NT, L.EPI_GELU, [self.prob(x_in[m], self.W(names[m]["up"] + ".weight"), h[m], self.st[m].M, I, H, H, H, I, bias=self.Pm(names[m]["up"] + ".bias"), C2=gp[m]) for m in ms])
+        self.gemm(f, L.NT, L.EPI_BF16, [self.prob(h[m], self.W(names[m]["down"] + ".weight"), d[m], self.st[m].M, H, I, I, I, H, bias=self.Pm(names[m]["down"] + ".bias")) for m in ms])
+        odrop = {}
+        for m in ms:
+            odrop[m] = self.drop(cfg.hidden_dropout_prob if m == 0 else cfg.v_hidden_dropout_prob)
+            f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(d[m], x_in[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", y[m], d[m], mean[m], rstd[m], self.st[m].M, odrop[m]), None, None))
+            self.x[m] = y[m]
+        b = []
+        dz, dd, du, dxn, dxi = {}, {}, {}, {}, {}
+        for i, m in enumerate(ms):
+            dxi[m], dxn[m] = self._dx_step(m)
+            acc = 1 if (shared and i > 0) else 0
+            dz[m] = self.tmp("dz%d" % m, (self.st[m].M, H))
+            dd[m] = self.tmp("dd%d" % m, (self.st[m].M, H)) if self.train else dz[m]
+            b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dxi[m], d[m], mean[m], rstd[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", dz[m],
+                                                              dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc), None, None))
+            du[m] = self.tmp("du%d" % m, (self.st[m].M, I))
+        self.gemm(b, L.NN, L.EPI_MULR, [self.prob(dd[m], self.W(names[m]["down"] + ".weight"), du[m], self.st[m].M, I, H, H, I, I, R=gp[m], ldr=I) for m in ms])
+        self._wgrad(b, ms, shared, lambda m: (dd[m], h[m], self.G(names[m]["down"] + ".weight"), self.G(names[m]["down"] + ".bias"), H, I, H, I))
+        self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(du[m], self.W(names[m]["up"] + ".weight"), dxn[m], self.st[m].M, H, I, I, H, H, R=dz[m], ldr=H) for m in ms])
+        self._wgrad(b, ms, shared, lambda m: (du[m], x_in[m], self.G(names[m]["up"] + ".weight"), self.G(names[m]["up"] + ".bias"), I, H, I, H))
+        return b
+
+    def _wgrad(self, b, ms, shared, spec):
+        """dW[Mo, No] = dY^T X (+ bias grad); weights shared by both modalities: second launch accumulates."""
+        probs = []
+        for m in ms:
+            dY, X, gW, gB, Mo, No, lda, ldb = spec(m)
+            probs.append(self.prob(dY, X, gW, Mo, No, self.st[m].M, lda, ldb, No, bias_grad=gB))
+        if shared and len(probs) == 2:
+            self.gemm(b, L.TN, L.EPI_F32, probs[:1])
+            self.gemm(b, L.TN, L.EPI_F32_ACC, probs[1:])
+        else:
+            self.gemm(b, L.TN, L.EPI_F32, probs)
+
+    # ---------------------------------------------------------------- heads + losses
+    def _heads(self):
+        cfg, B, H, T, Rv, R = self.cfg, self.B, self.H, self.T, self.Rv, self.R
+        f = self.fwd.ops
+        st_t, st_v = self.st
+        P = cfg.pooler_size
+        if P != cfg.v_pooler_size or P % 64:
+            raise NotImplementedError("pooler sizes must match and be multiples of 64")
+        V, Vp = cfg.vocab_size, _round_up(cfg.vocab_size, 64)
+        Cn, Cp = 1601, _round_up(1601, 64)
+        x_t, x_v = self.x
+        self.sums = self.buf("loss_sums", (4,), torch.float32)
+        self.losses = self.buf("losses", (3,), torch.float32)
+        self.gout = self.buf("gout", (3,), torch.float32)
+        f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MEMSET, p=(self.sums,), n=(16, 0)), None, None))
+        # ---- ITM: poolers, fusion, classifier
+        pt, pv = self.buf("pooled_t", (B, P)), self.buf("pooled_v", (B, P))
+        self.gemm(f, L.NT, L.EPI_RELU, [self.prob(x_t, self.W("bert.t_pooler.dense.weight"), pt, B, P, H, T * H, H, P, bias=self.Pm("bert.t_pooler.dense.bias")),
+                                        self.prob(x_v, self.W("bert.v_pooler.dense.weight"), pv, B, P, H, Rv * H, H, P, bias=self.Pm("bert.v_pooler.dense.bias"))])
+        # ---- masked LM on labelled rows
+        n_t, n_v = self.buf("n_t", (1,), torch.int32), self.buf("n_v", (1,), torch.int32)
+        rows_t, pos_t = self.buf("rows_t", (st_t.M,), torch.int32), self.buf("pos_t", (st_t.M,), torch.int32)
+        g = self.generic(L.FN_SELECT, p=(None, rows_t, pos_t, n_t), n=(st_t.M, 0, T, T, 0))
+        self.patch("masked_lm_labels", g, "p", 0)
+        f.append((L.OP_GENERIC, 0, 0, 0, g, None, None))
+        hx_t = self.buf("lm_hx", (st_t.M, H))
+        f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_GATHER, p=(x_t, rows_t, n_t, hx_t), n=(H, st_t.M)), None, None))
+        c = "cls.predictions."
+        ht, gpt = self.buf("lm_ht", (st_t.M, H)), self.buf("lm_gp", (st_t.M, H))
+        self.gemm(f, L.NT, L.EPI_GELU, [self.prob(hx_t, self.W(c + "transform.dense.weight"), ht, st_t.M, H, H, H, H, H, bias=self.Pm(c + "transform.dense.bias"), C2=gpt, dyn=n_t)])
+        hn_t = self.buf("lm_hn", (st_t.M, H))
+        lm_mean, lm_rstd = self.buf("lm_mean", (st_t.M,), torch.float32), self.buf("lm_rstd", (st_t.M,), torch.float32)
+        nodrop = L.dropout_cfg(None, 0, 0.0)
+        f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(ht, None, c + "transform.LayerNorm.weight", c + "transform.LayerNorm.bias", hn_t, None, lm_mean, lm_rstd, st_t.M, nodrop, dyn=n_t), None, None))
+        logits_t = self.buf("lm_logits", (st_t.M, Vp), torch.float32)
+        wword = "bert.embeddings.word_embeddings.weight"
+        self.gemm(f, L.NT, L.EPI_F32, [self.prob(hn_t, self.W(wword), logits_t, st_t.M, V, H, H, H, Vp, bias=self.Pm(c + "bias"), dyn=n_t, n_store=Vp)])
+        lse_t = self.buf("lm_lse", (st_t.M,), torch.float32)
+        xa = self.k(L.XentArgs(_addr(logits_t), None, _addr(pos_t), _addr(n_t), _addr(lse_t), _addr(self.sums[0:1]), V, Vp, st_t.M))
+        self.patch("masked_lm_labels", xa, "labels")
+        f.append((L.OP_XENT_FWD, 0, 0, 0, xa, None, None))
+        # ---- masked regions (kl_1601) on labelled rows
+        Mr = B * R
+        rows_v, pos_v = self.buf("rows_v", (Mr,), torch.int32), self.buf("pos_v", (Mr,), torch.int32)
+        off = 1 if cfg.add_global_imgfeat == "first" else 0
+        g = self.generic(L.FN_SELECT, p=(None, rows_v, pos_v, n_v), n=(Mr, 1, R, Rv, off))
+        self.patch("image_label", g, "p", 0)
+        f.append((L.OP_GENERIC, 0, 0, 0, g, None, None))
+        hx_v = self.buf("img_hx", (Mr, H))
+        f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_GATHER, p=(x_v, rows_v, n_v, hx_v), n=(H, Mr)), None, None))
+        ci = "cls.imagePredictions."
+        hv, gpv = self.buf("img_ht", (Mr, H)), self.buf("img_gp", (Mr, H))
+        self.gemm(f, L.NT, L.EPI_GELU, [self.prob(hx_v, self.W(ci + "transform.dense.weight"), hv, Mr, H, H, H, H, H, bias=self.Pm(ci + "transform.dense.bias"), C2=gpv, dyn=n_v)])
+        if cfg.image_head_ln:
+            hn_v = self.buf("img_hn", (Mr, H))
+            im_mean, im_rstd = self.buf("img_mean", (Mr,), torch.float32), self.buf("img_rstd", (Mr,), torch.float32)
+            f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(hv, None, ci + "transform.LayerNorm.weight", ci + "transform.LayerNorm.bias", hn_v, None, im_mean, im_rstd, Mr, nodrop, dyn=n_v), None, None))
+        else:
+            hn_v = hv
+        logits_v = self.buf("img_logits", (Mr, Cp), torch.float32)
+        self.gemm(f, L.NT, L.EPI_F32, [self.prob(hn_v, self.W(ci + "decoder_dict.0.weight"), logits_v, Mr, Cn, H, H, H, Cp, bias=self.Pm(ci + "decoder_dict.0.bias"), dyn=n_v, n_store=Cp)])
+        lse_v, tsum_v = self.buf("img_lse", (Mr,), torch.float32), self.buf("img_tsum", (Mr,), torch.float32)
+        kw = float(cfg.visual_target_weights["0"])
+        ka = self.k(L.KlArgs(_addr(logits_v), None, _addr(pos_v), _addr(n_v), _addr(lse_v), _addr(tsum_v), _addr(self.sums[1:2]), kw, Cn, Cp, Mr))
+        self.patch("image_cls", ka, "target")
+        f.append((L.OP_KL_FWD, 0, 0, 0, ka, None, None))
+        # ---- ITM head (its dropout site is the last one of the forward pass)
+        pooled = self.buf("pooled", (B, P))
+        pdrop = self.drop(0.1)
+        f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_POOL_FWD, p=(pt, pv, pooled), n=(B, P), drop=pdrop), None, None))
+        itm = self.buf("itm_logits", (B, 64), torch.float32)
+        self.gemm(f, L.NT, L.EPI_F32, [self.prob(pooled, self.W("cls.bi_seq_relationship.weight"), itm, B, 2, P, P, P, 64, bias=self.Pm("cls.bi_seq_relationship.bias"), n_store=64)])
+        lse_i = self.buf("itm_lse", (B,), torch.float32)
+        xi = self.k(L.XentArgs(_addr(itm), None, None, None, _addr(lse_i), _addr(self.sums[2:3]), 2, 64, B))
+        self.patch("next_sentence_label", xi, "labels")
+        f.append((L.OP_XENT_FWD, 0, 0, 0, xi, None, None))
+        f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_LOSS_FINAL, p=(self.sums, n_t, n_v, self.losses), n=(B,), f=(kw,)), None, None))
+        self.taps.update(seq_t=x_t, seq_v=x_v, pooled_t=pt, pooled_v=pv)
+
+        # ================= backward of the heads: produces dX[0], dX[1] (buffer 'a')
+        b = []
+        dxh = [self._dx(m, self.level[m] % 2) for m in range(2)]
+        for m in range(2):
+            b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MEMSET, p=(dxh[m],), n=(dxh[m].numel() * 2, 0)), None, None))
+        # LM
+        dlog_t = self.buf("lm_dlogits", (st_t.M, Vp))
+        b.append((L.OP_XENT_BWD, Vp, 0, 0, xa, dlog_t, self.gout[0:1]))
+        dhn_t = self.tmp("head_d1", (max(st_t.M, Mr), H))
+        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dlog_t, self.W(wword), dhn_t, st_t.M, H, V, Vp, H, H, dyn=n_t)])
+        self.gemm(b, L.TN, L.EPI_F32, [self.prob(dlog_t, hn_t, self.G(wword), V, H, st_t.M, Vp, H, H, bias_grad=self.G(c + "bias"), dyn=n_t)])
+        dht = self.tmp("head_d2", (max(st_t.M, Mr), H))
+        b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dhn_t, ht, lm_mean, lm_rstd, c + "transform.LayerNorm.weight", c + "transform.LayerNorm.bias", dht, None, st_t.M, nodrop, dyn=n_t), None, None))
+        du_t = self.tmp("head_d3", (max(st_t.M, Mr), H))
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MUL, p=(dht, gpt, du_t, n_t), n=(st_t.M * H, H)), None, None))
+        dhx_t = self.tmp("head_d1", (max(st_t.M, Mr), H))
+        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(du_t, self.W(c + "transform.dense.weight"), dhx_t, st_t.M, H, H, H, H, H, dyn=n_t)])
+        self.gemm(b, L.TN, L.EPI_F32, [self.prob(du_t, hx_t, self.G(c + "transform.dense.weight"), H, H, st_t.M, H, H, H, bias_grad=self.G(c + "transform.dense.bias"), dyn=n_t)])
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SCATTER_ADD, p=(dhx_t, rows_t, n_t, dxh[0]), n=(H, st_t.M)), None, None))
+        # image head
+        dlog_v = self.buf("img_dlogits", (Mr, Cp))
+        b.append((L.OP_KL_BWD, Cp, 0, 0, ka, dlog_v, self.gout[1:2]))
+        dhn_v = self.tmp("head_d1", (max(st_t.M, Mr), H))
+        wdec = ci + "decoder_dict.0."
+        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dlog_v, self.W(wdec + "weight"), dhn_v, Mr, H, Cn, Cp, H, H, dyn=n_v)])
+        self.gemm(b, L.TN, L.EPI_F32, [self.prob(dlog_v, hn_v, self.G(wdec + "weight"), Cn, H, Mr, Cp, H, H, bias_grad=self.G(wdec + "bias"), dyn=n_v)])
+        if cfg.image_head_ln:
+            dhv = self.tmp("head_d2", (max(st_t.M, Mr), H))
+            b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dhn_v, hv, im_mean, im_rstd, ci + "transform.LayerNorm.weight", ci + "transform.LayerNorm.bias", dhv, None, Mr, nodrop, dyn=n_v), None, None))
+        else:
+            dhv = dhn_v
+        du_v = self.tmp("head_d3", (max(st_t.M, Mr), H))
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MUL, p=(dhv, gpv, du_v, n_v), n=(Mr * H, H)), None, None))
+        dhx_v = self.tmp("head_d2" if not cfg.image_head_ln else "head_d1", (max(st_t.M, Mr), H))
+        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(du_v, self.W(ci + "transform.dense.weight"), dhx_v, Mr, H, H, H, H, H, dyn=n_v)])
+        self.gemm(b, L.TN, L.EPI_F32, [self.prob(du_v, hx_v, self.G(ci + "transform.dense.weight"), H, H, Mr, H, H, H, bias_grad=self.G(ci + "transform.dense.bias"), dyn=n_v)])
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SCATTER_ADD, p=(dhx_v, rows_v, n_v, dxh[1]), n=(H, Mr)), None, None))
+        # ITM
+        dlog_i = self.buf("itm_dlogits", (B, 64))
+        b.append((L.OP_XENT_BWD, 64, 0, 0, xi, dlog_i, self.gout[2:3]))
+        dpooled = self.buf("d_pooled", (B, P))
+        wi = "cls.bi_seq_relationship."
+        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dlog_i, self.W(wi + "weight"), dpooled, B, P, 2, 64, P, P)])
+        self.gemm(b, L.TN, L.EPI_F32, [self.prob(dlog_i, pooled, self.G(wi + "weight"), 2, P, B, 64, P, P, bias_grad=self.G(wi + "bias"))])
+        dyt, dyv = self.buf("d_pool_t", (B, P)), self.buf("d_pool_v", (B, P))
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_POOL_BWD, p=(dpooled, pt, pv, dyt, dyv), n=(B, P, P), drop=pdrop), None, None))
+        for m, (dy_, xm, Lm, pre) in enumerate(((dyt, x_t, T, "bert.t_pooler.dense."), (dyv, x_v, Rv, "bert.v_pooler.dense."))):
+            self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dy_, self.W(pre + "weight"), dxh[m], B, H, P, P, H, Lm * H, R=dxh[m], ldr=Lm * H)])
+            self.gemm(b, L.TN, L.EPI_F32, [self.prob(dy_, xm, self.G(pre + "weight"), P, H, B, P, Lm * H, H, bias_grad=self.G(pre + "bias"))])
+        return b
+
+    # ---------------------------------------------------------------- run
+    def bind_inputs(self, tensors):
+        """Patch the per-step input pointers into the few ops that read user tensors."""
+        for name, sites in self.inputs.items():
+            t = tensors[name]
+            addr = t.data_ptr()
+            for struct, field, index in sites:
+                if index is None:
+                    setattr(struct, field, addr)
+                else:
+                    getattr(struct, field)[index] = addr
+
+    def prepare_step(self, seed):
+        if self.train:
+            check(L.lib.vk_set_seed(ptr(self.seed), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), L.stream_ptr()))
+        v = getattr(self, "_visualbert_vec", None)
+        if v is not None:
+            vec, pre = v
+            torch.add(self.Pm(pre + "position_embeddings_visual.weight")[0], self.Pm(pre + "token_type_embeddings_visual.weight")[1], out=vec)
+
+
+def _mk_segs(drop, segs):
+    arr = (L.DropRows * 2)()
+    if segs is None:
+        segs = [(drop.site, 0, 0, 0), (drop.site + 1, 0, 0, 0)]
+    for i, sg in enumerate(segs):
+        arr[i] = L.DropRows(*sg)
+    return arr

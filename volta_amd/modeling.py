@@ -1,0 +1,354 @@
+"""Drop-in model classes: same constructor / forward signatures, parameter names and error behaviour as the
+reference's `BertModel` / `BertForVLPreTraining` (volta/encoders.py:918-1114, volta/utils.py:250-360), with the
+whole forward + backward dispatched to the HIP engine (volta_amd/engine.py).  There is no eager / CPU
+fallback: without a GPU and libvolta_hip.so the forward raises.
+
+Differences a caller can observe, all deliberate:
+  * the three losses come back from one fused step; the two host synchronisations of the reference
+    (encoders.py:1089, 1111) do not happen -- `img_loss` is numerically 0 when no region is labelled;
+  * activations are bf16 with fp32 accumulation / statistics (north_star), parameters stay fp32;
+  * dropout uses a counter-based Philox stream seeded from `torch.initial_seed()` (or `set_dropout_seed`).
+"""
+import os
+
+import torch
+from torch import nn
+
+from . import modules as M
+from .config import BertConfig
+
+
+class PreTrainedModel(nn.Module):
+    """Base with the helpers the reference's driver touches (volta/utils.py:250-360)."""
+
+    config_class = BertConfig
+    base_model_prefix = "bert"
+
+    def __init__(self, config, *inputs, **kwargs):
+        super().__init__()
+        self.config = config
+
+    def init_weights(self, module):
+        M.init_bert_(module, self.config.initializer_range)
+
+    def _get_resized_embeddings(self, old_embeddings, new_num_tokens=None):
+        if new_num_tokens is None:
+            return old_embeddings
+        old_num_tokens, dim = old_embeddings.weight.size()
+        if old_num_tokens == new_num_tokens:
+            return old_embeddings
+        new = M.TableParams(new_num_tokens, dim).to(old_embeddings.weight.device)
+        new.weight.data.normal_(mean=0.0, std=self.config.initializer_range)
+        n = min(old_num_tokens, new_num_tokens)
+        new.weight.data[:n, :] = old_embeddings.weight.data[:n, :]
+        self._invalidate_engine()
+        return new
+
+    def _tie_or_clone_weights(self, first_module, second_module):
+        first_module.weight = second_module.weight
+
+    def _invalidate_engine(self):
+        root = getattr(self, "_root", None) or self
+        root.__dict__["_arena"] = None
+        root.__dict__["_engines"] = {}
+
+    def _apply(self, fn, *a, **k):
+        out = super()._apply(fn, *a, **k)       # .cuda() / .to() / .float(): parameters are re-allocated
+        self._invalidate_engine()
+        return out
+
+    def save_pretrained(self, save_directory):
+        assert os.path.isdir(save_directory), "Saving path should be a directory where the model and configuration can be saved"
+        model_to_save = self.module if hasattr(self, "module") else self
+        with open(os.path.join(save_directory, "config.json"), "w", encoding="utf-8") as f:
+            f.write(model_to_save.config.to_json_string())
+        torch.save({k: v.detach().cpu().clone() for k, v in model_to_save.state_dict().items()},
+                   os.path.join(save_directory, "pytorch_model.bin"))
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, *model_args, config=None, state_dict=None, **kwargs):
+        """Local directory / file branch of the reference loader (volta/utils.py:419-430, 455-550).  Named
+        archives would need the network (utils.py:417-418) and are refused."""
+        kwargs.pop("default_gpu", None)
+        from_hf = kwargs.pop("from_hf", False)
+        path = pretrained_model_name_or_path
+        if os.path.isdir(path):
+            path = os.path.join(path, "pytorch_model.bin")
+        if state_dict is None:
+            if not os.path.isfile(path):
+                raise EnvironmentError("'%s' is not a local checkpoint; downloading named archives is not available "
+                                       "offline (volta/utils.py:417-418)" % pretrained_model_name_or_path)
+            state_dict = torch.load(path, map_location="cpu")
+        if from_hf:
+            raise NotImplementedError("HF-BERT key renumbering (volta/utils.py:475-498) is a 'next' item (SURVEY.md 8f-1)")
+        model = cls(config, *model_args, **kwargs)
+        sd = {}
+        for k, v in state_dict.items():
+            k = k.replace("gamma", "weight") if k.endswith("gamma") else k
+            k = k.replace("beta", "bias") if k.endswith("beta") else k
+            sd[k[len("module."):] if k.startswith("module.") else k] = v
+        missing, unexpected = model.load_state_dict(sd, strict=False)
+        if missing:
+            print("Weights of {} not initialized from pretrained model: {}".format(cls.__name__, missing))
+        if unexpected:
+            print("Weights from pretrained model not used in {}: {}".format(cls.__name__, unexpected))
+        if hasattr(model, "tie_weights"):
+            model.tie_weights()
+        model.eval()
+        return model
+
+
+class BertEncoder(M.Holder):
+    def __init__(self, config):
+        super().__init__()
+        self.num2type = {}
+        layers = []
+        for n, typ in M.sublayer_schedule(config):
+            self.num2type[n] = typ
+            layers.append(M.build_attention_sublayer(config, n) if typ == "attn" else M.build_ffn_sublayer(config, n))
+        self.layer = nn.ModuleList(layers)
+
+
+class BertModel(PreTrainedModel):
+    """Embeddings + gated encoder + poolers (volta/encoders.py:918-1017)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        kind = config.image_embeddings
+        self.shared_embeddings = kind in M.SHARED
+        if config.model != "bert":
+            raise NotImplementedError("RoBERTa embeddings are out of scope (SURVEY.md 2.1 #3)")
+        if kind in M.DUAL:
+            self.embeddings = M.build(M.EMBEDDING_SPECS["text"], config)
+            self.v_embeddings = M.build(M.EMBEDDING_SPECS[kind], config)
+        elif kind == "vl-bert":
+            self.embeddings = M.build_vlbert_embeddings(config)
+        elif kind in M.SHARED:
+            self.embeddings = M.build(M.EMBEDDING_SPECS[kind], config)
+        else:
+            raise ValueError("unknown image_embeddings %r" % kind)
+        self.encoder = BertEncoder(config)
+        self.fusion_method = config.fusion_method
+        if config.fusion_method != "mul":
+            raise NotImplementedError("fusion_method %r: only 'mul' (all ctrl_* configs) is on the hot path" % config.fusion_method)
+        assert config.pooler_size == config.v_pooler_size, "pooler_size != v_pooler_size"
+        self.t_pooler, self.v_pooler = M.Holder(), M.Holder()
+        self.t_pooler.add_module("dense", M.LinearParams(config.hidden_size, config.pooler_size))
+        self.v_pooler.add_module("dense", M.LinearParams(config.v_hidden_size, config.v_pooler_size))
+        M.init_bert_(self, config.initializer_range)
+        M.special_init_embeddings_(self.embeddings, kind, config)
+
+    def forward(self, input_txt, input_imgs, image_loc, token_type_ids=None, attention_mask=None,
+                image_attention_mask=None, output_all_encoded_layers=False, output_all_attention_masks=False):
+        root = self.__dict__.get("_root")
+        if root is None:
+            raise NotImplementedError("BertModel runs as part of BertForVLPreTraining (the HIP plan includes the heads)")
+        if output_all_encoded_layers or output_all_attention_masks:
+            raise NotImplementedError("intermediate layer / attention-map outputs are not materialised by the fused engine")
+        return root.encode(input_txt, input_imgs, image_loc, token_type_ids, attention_mask, image_attention_mask)
+
+
+class BertPreTrainingHeads(M.Holder):
+    """cls.predictions / cls.bi_seq_relationship / cls.imagePredictions (volta/encoders.py:643-764)."""
+
+    def __init__(self, config, bert_model_embedding_weights):
+        super().__init__()
+        H, Hv = config.hidden_size, config.v_hidden_size
+        pred, tr = M.Holder(), M.Holder()
+        tr.add_module("dense", M.LinearParams(H, H))
+        tr.add_module("LayerNorm", M.LayerNormParams(H))
+        pred.add_module("transform", tr)
+        dec = M.Holder()
+        dec.weight = bert_model_embedding_weights            # tied (encoders.py:691)
+        pred.add_module("decoder", dec)
+        pred.bias = nn.Parameter(torch.zeros(bert_model_embedding_weights.size(0)))
+        self.add_module("predictions", pred)
+        self.add_module("bi_seq_relationship", M.LinearParams(config.pooler_size, 2))
+        img, itr = M.Holder(), M.Holder()
+        itr.add_module("dense", M.LinearParams(Hv, Hv))
+        if config.image_head_ln:
+            itr.add_module("LayerNorm", M.LayerNormParams(Hv))
+        img.add_module("transform", itr)
+        widths = {"0": 1601, "1": 2048, "2": 2048, "3": 1600, "4": 400, "5": 2048, "6": 1601}   # losses.py:129-137
+        img.add_module("decoder_dict", nn.ModuleDict({ix: M.LinearParams(Hv, n) for ix, n in widths.items()
+                                                       if config.visual_target_weights.get(ix, 0) > 0}))
+        self.add_module("imagePredictions", img)
+        self.fusion_method = config.fusion_method
+        M.init_heads_(self)
+
+
+class _PretrainStep(torch.autograd.Function):
+    """One autograd node for the whole model: forward = engine forward list, backward = engine backward list.
+    Parameter gradients are written straight into the flat gradient arena and attached as `.grad` views."""
+
+    @staticmethod
+    def forward(ctx, model, anchor, tensors):
+        losses = model._engine_forward(tensors)
+        ctx.model = model
+        return losses[0:1].clone(), losses[1:2].clone(), losses[2:3].clone()
+
+    @staticmethod
+    def backward(ctx, g_lm, g_img, g_nsp):
+        ctx.model._engine_backward(g_lm, g_img, g_nsp)
+        return None, None, None
+
+
+class BertForVLPreTraining(PreTrainedModel):
+    """BERT model with multimodal pre-training heads (volta/encoders.py:1020-1114)."""
+
+    def __init__(self, config):
+        super().__init__(config)
+        self.bert = BertModel(config)
+        self.cls = BertPreTrainingHeads(config, self.bert.embeddings.word_embeddings.weight)
+        self.visual_target_weights = config.visual_target_weights
+        print("model's visual targets are ", [ix for ix, w in config.visual_target_weights.items() if w > 0])
+        self.add_global_imgfeat = int(config.add_global_imgfeat is not None)
+        self.tie_weights()
+        self.__dict__["_arena"] = None
+        self.__dict__["_engines"] = {}
+        self.__dict__["_step"] = 0
+        self.__dict__["_seed_base"] = None
+        self.__dict__["_last"] = None
+        self.__dict__["_ddp"] = None
+        self.bert.__dict__["_root"] = self
+        for mod in self.modules():
+            if mod is not self and isinstance(mod, PreTrainedModel):
+                mod.__dict__["_root"] = self
+
+    def tie_weights(self):
+        self._tie_or_clone_weights(self.cls.predictions.decoder, self.bert.embeddings.word_embeddings)
+
+    # ------------------------------------------------------------------ engine plumbing
+    def set_dropout_seed(self, seed):
+        self.__dict__["_seed_base"] = int(seed)
+        self.__dict__["_step"] = 0
+
+    def materialize(self, device=None):
+        """Build (or rebuild) the flat parameter arenas on `device`; parameters become views of them."""
+        from .engine import ParamArena
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("volta_amd runs on an MI355X only: move the model to the GPU first (model.cuda()); "
+                               "there is no CPU execution path")
+        arena = self.__dict__.get("_arena")
+        if arena is None or arena.device != dev or not arena.intact():
+            self.__dict__["_arena"] = ParamArena(self, dev)
+            self.__dict__["_engines"] = {}
+            for p in self.parameters():
+                p._vk_owner = self
+        return self.__dict__["_arena"]
+
+    def _engine(self, B, T, Rv, train):
+        from .engine import StepEngine
+        arena = self.materialize()
+        key = (B, T, Rv, bool(train))
+        eng = self._engines.get(key)
+        if eng is None:
+            for k in [k for k in self._engines if k[3] == key[3]]:      # one plan per mode keeps memory bounded
+                del self._engines[k]
+            eng = StepEngine(self.config, arena, B, T, Rv, train)
+            self._engines[key] = eng
+        return eng
+
+    def _prep_inputs(self, input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask,
+                     masked_lm_labels, image_label, image_cls, next_sentence_label):
+        dev = next(self.parameters()).device
+        B, T = input_ids.shape
+        Rv = image_feat.shape[1]
+        i64 = dict(device=dev, dtype=torch.int64)
+        f32 = dict(device=dev, dtype=torch.float32)
+        if attention_mask is None:
+            attention_mask = torch.ones(B, T, **i64)
+        if token_type_ids is None:
+            token_type_ids = torch.zeros(B, T, **i64)
+        if image_attention_mask is None:
+            image_attention_mask = torch.ones(B, Rv, **i64)
+        R = Rv - self.add_global_imgfeat
+        t = dict(input_ids=input_ids.to(**i64).contiguous(), token_type_ids=token_type_ids.to(**i64).contiguous(),
+                 attention_mask=attention_mask.to(**i64).contiguous(), image_attention_mask=image_attention_mask.to(**i64).contiguous(),
+                 image_feat=image_feat.to(**f32).contiguous(), image_loc=image_loc.to(**f32).contiguous())
+        assert t["image_feat"].shape == (B, Rv, self.config.v_feature_size), "image_feat must be [B, regions, v_feature_size]"
+        assert t["image_loc"].shape == (B, Rv, self.config.num_locs), "image_loc must be [B, regions, num_locs]"
+        if masked_lm_labels is not None:
+            t["masked_lm_labels"] = masked_lm_labels.to(**i64).contiguous()
+            t["image_label"] = image_label.to(**i64).contiguous()
+            t["image_cls"] = image_cls.to(**f32).contiguous()
+            t["next_sentence_label"] = next_sentence_label.to(**i64).contiguous()
+            assert t["masked_lm_labels"].shape == (B, T) and t["image_label"].shape == (B, R)
+            assert t["image_cls"].shape == (B, R, 1601) and t["next_sentence_label"].numel() == B
+            # ids / labels are range-clamped inside the kernels: no host synchronisation on the hot path
+        return t, B, T, Rv
+
+    def _engine_forward(self, tensors):
+        B, T = tensors["input_ids"].shape
+        Rv = tensors["image_feat"].shape[1]
+        eng = self._engine(B, T, Rv, self.training)
+        eng.arena.refresh_shadow()
+        eng.bind_inputs(tensors)
+        if self._seed_base is None:
+            self.__dict__["_seed_base"] = int(torch.initial_seed())
+        eng.prepare_step(self._seed_base + self._step)
+        self.__dict__["_step"] += 1
+        eng.fwd.run()
+        self.__dict__["_last"] = (eng, tensors)      # keeps the step's input tensors alive until backward
+        return eng.losses
+
+    def _engine_backward(self, g_lm, g_img, g_nsp):
+        eng, tensors = self._last
+        arena = eng.arena
+        params = list(arena.params.items())
+        have = [p.grad is not None for _, p in params]
+        accumulate = all(have)
+        if any(have) and not accumulate:
+            raise RuntimeError("volta_amd: some parameters carry a .grad and some do not; zero_grad() all of them")
+        if accumulate:
+            if not all(p.grad.data_ptr() == arena.view(n, "grad").data_ptr() for n, p in params):
+                raise RuntimeError("volta_amd: .grad tensors were replaced by foreign tensors; call zero_grad(set_to_none=True)")
+            old = arena.grad.clone()
+        eng.gout.copy_(torch.cat([g_lm.reshape(1), g_img.reshape(1), g_nsp.reshape(1)]).to(eng.gout))
+        ddp = self.__dict__.get("_ddp")
+        if ddp is not None:
+            ddp.run_backward(eng)
+        else:
+            eng.bwd.run()
+        if accumulate:
+            from . import _lib as L
+            L.check(L.lib.vk_axpy_f32(L.ptr(arena.grad), L.ptr(old), 1.0, arena.total, L.stream_ptr()))
+        else:
+            for n, p in params:
+                p.grad = arena.view(n, "grad")
+
+    # ------------------------------------------------------------------ public API
+    def forward(self, input_ids, image_feat, image_loc, token_type_ids=None, attention_mask=None,
+                image_attention_mask=None, masked_lm_labels=None, image_label=None, image_cls=None, obj_labels=None,
+                obj_confs=None, attr_labels=None, attr_confs=None, image_attrs=None, next_sentence_label=None,
+                output_all_attention_masks=False):
+        if output_all_attention_masks:
+            raise NotImplementedError("attention maps are never materialised by the fused attention kernel")
+        if masked_lm_labels is None or image_label is None or image_cls is None or next_sentence_label is None:
+            raise NotImplementedError("the pre-training step needs masked_lm_labels, image_label, image_cls and "
+                                      "next_sentence_label (the score-returning branch of encoders.py:1113-1114 is not on the hot path)")
+        tensors, B, T, Rv = self._prep_inputs(input_ids, image_feat, image_loc, token_type_ids, attention_mask,
+                                              image_attention_mask, masked_lm_labels, image_label, image_cls, next_sentence_label)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            self.materialize()
+            anchor = next(p for p in self.parameters() if p.requires_grad)
+            return _PretrainStep.apply(self, anchor, tensors)
+        losses = self._engine_forward(tensors)
+        return losses[0:1].clone(), losses[1:2].clone(), losses[2:3].clone()
+
+    def encode(self, input_ids, image_feat, image_loc, token_type_ids=None, attention_mask=None, image_attention_mask=None):
+        """BertModel.forward: (seq_t [B,T,H], seq_v [B,Rv,H], pooled_t, pooled_v, attention maps = ([], []))."""
+        B, T = input_ids.shape
+        R = image_feat.shape[1] - self.add_global_imgfeat
+        dev = next(self.parameters()).device
+        dummy = dict(masked_lm_labels=torch.full((B, T), -1, dtype=torch.int64, device=dev),
+                     image_label=torch.full((B, R), -1, dtype=torch.int64, device=dev),
+                     image_cls=torch.zeros(B, R, 1601, device=dev), next_sentence_label=torch.zeros(B, dtype=torch.int64, device=dev))
+        tensors, B, T, Rv = self._prep_inputs(input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask, **dummy)
+        with torch.no_grad():
+            self._engine_forward(tensors)
+        eng = self._last[0]
+        H = self.config.hidden_size
+        return (eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, H).float(),
+                eng.taps["pooled_t"].float(), eng.taps["pooled_v"].float(), ([], []))

@@ -61,27 +61,41 @@ def set_seed(seed_t, value):
     check(L.lib.vk_set_seed(ptr(seed_t), C.c_uint64(value & 0xFFFFFFFFFFFFFFFF), stream_ptr()))
 
 
-def ln_fwd(d, x, gamma, beta, y, z, mean, rstd, M, H, drop=None, split_row=None, post=0, out_scale=1.0):
+def _segs(drop, segs):
+    """segs: None -> identity rows on drop.site; else [(site, div, mul, off), (site, div, mul, off)]."""
+    arr = (L.DropRows * 2)()
+    if segs is None:
+        site = drop.site if drop is not None else 0
+        segs = [(site, 0, 0, 0), (site + 1, 0, 0, 0)]
+    for i, sg in enumerate(segs):
+        arr[i] = L.DropRows(*sg)
+    return arr
+
+
+def ln_fwd(d, x, gamma, beta, y, z, mean, rstd, M, H, drop=None, split_row=None, post=0, out_scale=1.0, addvec=None,
+           dyn=None, segs=None):
     for t in (d, y):
         _bf16(t)
         assert t.numel() >= M * H
     assert gamma.dtype == torch.float32 and gamma.numel() == H and beta.numel() == H
     assert mean.numel() >= M and rstd.numel() >= M and mean.dtype == torch.float32
-    a = L.LnArgs(ptr(d), ptr(x), ptr(gamma), ptr(beta), ptr(y), ptr(z), ptr(mean), ptr(rstd), M, H,
-                 split_row if split_row is not None else M, post, out_scale, drop or L.dropout_cfg(None, 0, 0.0))
+    drop = drop or L.dropout_cfg(None, 0, 0.0)
+    a = L.LnArgs(ptr(d), ptr(x), ptr(addvec), ptr(gamma), ptr(beta), ptr(y), ptr(z), ptr(mean), ptr(rstd), ptr(dyn), M, H,
+                 split_row if split_row is not None else M, post, out_scale, drop, _segs(drop, segs))
     check(L.lib.vk_ln_fwd(C.byref(a), stream_ptr()))
 
 
 def ln_bwd(dy, z, mean, rstd, gamma, dz, dd, partial, dgamma, dbeta, M, H, drop=None, split_row=None, post=0,
-           out_scale=1.0):
+           out_scale=1.0, dyn=None, segs=None):
     for t in (dy, z, dz):
         _bf16(t)
         assert t.numel() >= M * H
     assert partial.numel() >= L.lib.vk_ln_bwd_partial_rows(M) * 2 * H and partial.dtype == torch.float32
     assert dgamma.numel() == H and dbeta.numel() == H
+    drop = drop or L.dropout_cfg(None, 0, 0.0)
     a = L.LnBwdArgs(ptr(dy), ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(dz), ptr(dd), ptr(partial), ptr(dgamma),
-                    ptr(dbeta), M, H, split_row if split_row is not None else M, post, out_scale,
-                    drop or L.dropout_cfg(None, 0, 0.0))
+                    ptr(dbeta), ptr(dyn), M, H, split_row if split_row is not None else M, post, out_scale, 0, drop,
+                    _segs(drop, segs))
     check(L.lib.vk_ln_bwd(C.byref(a), stream_ptr()))
 
 

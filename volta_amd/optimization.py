@@ -1,0 +1,145 @@
+"""Optimizer-side drop-ins for the reference's pre-training driver (train_concap.py:21,227-234,307-311):
+
+  AdamW                  pytorch_transformers.optimization.AdamW  (same constructor / param-group semantics)
+  WarmupLinearSchedule   pytorch_transformers.optimization.WarmupLinearSchedule
+  clip_grad_norm_        torch.nn.utils.clip_grad_norm_
+
+All parameters of a volta_amd model are views of one flat arena, so `step()` is ONE fused kernel over
+(p, g, m, v) that also refreshes the bf16 weight copies used by the GEMMs, and the gradient norm / clip
+coefficient never leave the device.  The arithmetic (decay after the Adam update with the un-corrected lr,
+eps outside the bias correction) follows pytorch-transformers 1.1.0 and is pinned by the oracle tests."""
+import ctypes as C
+import math
+
+import torch
+from torch.optim import Optimizer
+from torch.optim.lr_scheduler import LambdaLR
+
+from . import _lib as L
+
+
+def _arena_of(params):
+    owners = {id(getattr(p, "_vk_owner", None)): getattr(p, "_vk_owner", None) for p in params}
+    if len(owners) != 1 or None in owners.values():
+        raise RuntimeError("volta_amd optimizers need parameters owned by one volta_amd model on the GPU: call "
+                           "model.cuda() and model.materialize() (or run one forward) before building the optimizer")
+    model = next(iter(owners.values()))
+    arena = model.materialize()
+    return model, arena
+
+
+class AdamW(Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+        if lr < 0.0:
+            raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
+        if not 0.0 <= betas[0] < 1.0:
+            raise ValueError("Invalid beta parameter: {} - should be in [0.0, 1.0[".format(betas[0]))
+        if not 0.0 <= betas[1] < 1.0:
+            raise ValueError("Invalid beta parameter: {} - should be in [0.0, 1.0[".format(betas[1]))
+        if not 0.0 <= eps:
+            raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(eps))
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
+        self._fused = None
+
+    def _setup(self):
+        allp = [p for g in self.param_groups for p in g["params"]]
+        model, arena = _arena_of(allp)
+        opt_ptrs = {p.data_ptr() for p in allp}
+        if len(opt_ptrs) != len(arena.params):
+            raise RuntimeError("volta_amd.AdamW: pass every parameter of the model (frozen subsets are not supported yet)")
+        byptr = {p.data_ptr(): n for n, p in arena.params.items()}
+        # classes: groups with identical (initial lr, wd, betas, eps, correct_bias) share one class
+        classes, cls_of_chunk = [], torch.zeros(arena.total // 1024, dtype=torch.uint8)
+        hyper = None
+        for g in self.param_groups:
+            h = (tuple(g["betas"]), g["eps"], g["correct_bias"])
+            hyper = hyper or h
+            if h != hyper:
+                raise RuntimeError("volta_amd.AdamW: betas / eps / correct_bias must be common to all groups")
+            key = (g.get("initial_lr", g["lr"]), g["weight_decay"])
+            if key not in [c[0] for c in classes]:
+                if len(classes) == 8:
+                    raise RuntimeError("volta_amd.AdamW: more than 8 distinct (lr, weight_decay) classes")
+                classes.append((key, g))
+            ci = [c[0] for c in classes].index(key)
+            for p in g["params"]:
+                n = byptr[p.data_ptr()]
+                numel = 1
+                for d in arena.shape[n]:
+                    numel *= d
+                c0 = arena.offset[n] // 1024
+                c1 = (arena.offset[n] + numel + 1023) // 1024
+                cls_of_chunk[c0:c1] = ci
+        self._fused = dict(model=model, arena=arena, classes=classes, chunk_class=cls_of_chunk.to(arena.device),
+                           m=torch.zeros_like(arena.master), v=torch.zeros_like(arena.master), step=0)
+
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = closure() if closure is not None else None
+        if self._fused is None:
+            self._setup()
+        f = self._fused
+        arena = f["arena"]
+        f["step"] += 1
+        g0 = self.param_groups[0]
+        b1, b2 = g0["betas"]
+        a = L.AdamwArgs()
+        a.p, a.g, a.m, a.v = arena.master.data_ptr(), arena.grad.data_ptr(), f["m"].data_ptr(), f["v"].data_ptr()
+        a.shadow, a.chunk_class = arena.shadow.data_ptr(), f["chunk_class"].data_ptr()
+        clip = getattr(arena, "pending_clip", None)
+        a.clip = clip.data_ptr() if clip is not None else None
+        arena.pending_clip = None
+        a.n = arena.total
+        for i, (key, grp) in enumerate(f["classes"]):
+            a.cls_lr_mult[i] = grp["lr"]          # current (scheduled) lr of the class
+            a.cls_wd[i] = grp["weight_decay"]
+        a.lr, a.beta1, a.beta2, a.eps = 1.0, b1, b2, g0["eps"]
+        t = f["step"]
+        a.step_mult = math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t) if g0["correct_bias"] else 1.0
+        a.grad_scale = grad_scale
+        L.check(L.lib.vk_adamw_step(C.byref(a), L.stream_ptr()))
+        arena.shadow_version = arena.master._version      # the kernel refreshed the bf16 copies itself
+        return loss
+
+    def zero_grad(self, set_to_none=True):
+        for g in self.param_groups:
+            for p in g["params"]:
+                if set_to_none:
+                    p.grad = None
+                elif p.grad is not None:
+                    p.grad.zero_()
+
+
+class WarmupLinearSchedule(LambdaLR):
+    """Linear warm-up from 0 to 1 over `warmup_steps`, then linear decay to 0 at `t_total`."""
+
+    def __init__(self, optimizer, warmup_steps, t_total, last_epoch=-1):
+        self.warmup_steps = warmup_steps
+        self.t_total = t_total
+        super().__init__(optimizer, self.lr_lambda, last_epoch=last_epoch)
+
+    def lr_lambda(self, step):
+        if step < self.warmup_steps:
+            return float(step) / float(max(1, self.warmup_steps))
+        return max(0.0, float(self.t_total - step) / float(max(1.0, self.t_total - self.warmup_steps)))
+
+
+def clip_grad_norm_(parameters, max_norm, norm_type=2.0, defer_to_optimizer=False, pre_scale=1.0):
+    """Global L2 norm of the gradients and clipping by max_norm / (norm + 1e-6) when that is < 1.
+    Returns the norm as a 0-dim DEVICE tensor (no host synchronisation).  With `defer_to_optimizer` the
+    coefficient is handed to the next AdamW.step(), which folds it into its single pass over the gradients."""
+    if float(norm_type) != 2.0:
+        raise NotImplementedError("only the L2 norm is supported")
+    params = [parameters] if isinstance(parameters, torch.Tensor) else list(parameters)
+    model, arena = _arena_of(params)
+    if any(p.grad is None or p.grad.data_ptr() != arena.view(n, "grad").data_ptr() for n, p in arena.params.items()):
+        raise RuntimeError("clip_grad_norm_: gradients are not attached to the engine's arena (run backward first)")
+    if not hasattr(arena, "norm_ws"):
+        arena.norm_ws = torch.empty(L.lib.vk_grad_norm_workspace_floats(), device=arena.device)
+    out = torch.empty(2, device=arena.device)
+    L.check(L.lib.vk_grad_norm_clip(L.ptr(arena.grad), arena.total, pre_scale, float(max_norm), L.ptr(arena.norm_ws), L.ptr(out), L.stream_ptr()))
+    if defer_to_optimizer:
+        arena.pending_clip = out
+    else:
+        arena.grad.mul_(out[1])
+    return out[0]
