@@ -10,6 +10,17 @@ def _mods():
     return L, ops
 
 
+@pytest.fixture(params=[0, 128, 192, 256], ids=["auto", "tile128x128", "tile256x128", "tile256x256"], autouse=True)
+def tile_edge(request):
+    """Every GEMM test runs under the tile heuristic and with each tile geometry forced."""
+    import ctypes
+    from volta_amd import _lib as L
+    L.lib.vk_gemm_set_tile.argtypes = [ctypes.c_int]
+    L.lib.vk_gemm_set_tile(request.param)
+    yield request.param
+    L.lib.vk_gemm_set_tile(0)
+
+
 def rnd(shape, g, scale=1.0):
     return (torch.randn(shape, generator=g, device="cuda") * scale).to(torch.bfloat16)
 

@@ -172,13 +172,20 @@ __global__ __launch_bounds__(256) void loc_linear_bwd_kernel(const uint16_t* dz,
     }
 }
 // dW[n][k] = sum_blk partial[blk][k][n] ; db[n] = sum_blk partial[blk][8][n]
-__global__ void loc_linear_bwd_finalize_kernel(const float* partial, int nblk, int H, int nloc, float* dW, float* db) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 9 * H) return;
+__global__ __launch_bounds__(1024) void loc_linear_bwd_finalize_kernel(const float* partial, int nblk, int H, int nloc, float* dW, float* db) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
+    float s = 0.f;
+    if (i < 9 * H)
+        for (int b = ty; b < nblk; b += 16) s += partial[(size_t)b * 9 * H + i];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty != 0 || i >= 9 * H) return;
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][tx];
     const int k = i / H, n = i - k * H;
     if (k < 8 && k >= nloc) return;
-    float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * 9 * H + i];
     if (k == 8) db[n] = s; else dW[(size_t)n * nloc + k] = s;
 }
 
@@ -237,11 +244,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const uint16_t* src, float*
     __syncthreads();
     for (int c = threadIdx.x; c < H; c += 256) partial[(size_t)blockIdx.x * H + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
 }
-__global__ void colsum_finalize_kernel(const float* partial, int nblk, int H, float* out, int accumulate) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= H) return;
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* partial, int nblk, int H, float* out, int accumulate) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * H + c];
+    if (c < H)
+        for (int b = ty; b < nblk; b += 16) s += partial[(size_t)b * H + c];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty != 0 || c >= H) return;
+#pragma unroll
+    for (int k = 1; k < 16; ++k) s += red[k][tx];
     out[c] = accumulate ? out[c] + s : s;
 }
 
@@ -297,7 +311,7 @@ extern "C" int vk_loc_linear_bwd(const void* dz, const float* loc, float* partia
         case 3: hipLaunchKernelGGL(loc_linear_bwd_kernel<3>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)dz, loc, partial, M, H, nloc); break;
         default: hipLaunchKernelGGL(loc_linear_bwd_kernel<4>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)dz, loc, partial, M, H, nloc); break;
     }
-    hipLaunchKernelGGL(loc_linear_bwd_finalize_kernel, dim3((9 * H + 255) / 256), dim3(256), 0, st, partial, nblk, H, nloc, dW, db);
+    hipLaunchKernelGGL(loc_linear_bwd_finalize_kernel, dim3((9 * H + 63) / 64), dim3(1024), 0, st, partial, nblk, H, nloc, dW, db);
     return check_launch("vk_loc_linear_bwd");
 }
 
@@ -320,6 +334,6 @@ extern "C" int vk_colsum_bf16(const void* src, float* partial, float* out, int M
         case 3: hipLaunchKernelGGL(colsum_kernel<3>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)src, partial, M, H); break;
         default: hipLaunchKernelGGL(colsum_kernel<4>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)src, partial, M, H); break;
     }
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((H + 255) / 256), dim3(256), 0, st, partial, nblk, H, out, accumulate);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((H + 63) / 64), dim3(1024), 0, st, partial, nblk, H, out, accumulate);
     return check_launch("vk_colsum_bf16");
 }

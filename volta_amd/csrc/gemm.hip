@@ -1,26 +1,35 @@
-// Grouped bf16 GEMM for gfx950: 128x128x64 tiles, 4 waves (2x2) x 64x64 wave tiles of
-// v_mfma_f32_16x16x32_bf16, operands staged HBM -> LDS by bounds-checked LDS-DMA
-// (buffer_load ... lds, 16 B/lane), double-buffered.  Three operand layouts share one skeleton:
-//   NT  both operands K-contiguous            -> fragments by ds_read_b128 (XOR-swizzled image)
+// Grouped bf16 GEMM for gfx950 (v_mfma_f32_16x16x32_bf16, fp32 accumulate).  One kernel skeleton, three
+// operand layouts, two tile geometries, fused epilogues:
+//   NT  both operands K-contiguous            -> fragments by ds_read_b128 from an XOR-swizzled image
 //   NN  B stored [K][N]                       -> B fragments by ds_read_b64_tr_b16 (hardware transpose)
 //   TN  A stored [K][M], B stored [K][N]      -> both by ds_read_b64_tr_b16
-// The swizzle lives on the per-lane GLOBAL source address (LDS-DMA writes LDS linearly) and on the
-// read address (cdna guide rule 21).  MFMA operands are swapped (D = B-frag x A-frag) so that every
-// lane owns 4 consecutive output columns of one output row: 8-byte bf16 / 16-byte fp32 stores.
+// Geometry: WM x WN waves, each owning a 64 x 64 output sub-tile (4 x 4 MFMA tiles), BK = 64:
+//   2 x 2 = 128 x 128 tile,  256 threads, 32 KiB LDS per stage, 2 workgroups / CU
+//   4 x 2 = 256 x 128 tile,  512 threads, 48 KiB LDS per stage, 1 workgroup / CU (2 waves / SIMD)
+//   4 x 4 = 256 x 256 tile, 1024 threads, 64 KiB LDS per stage, 1 workgroup / CU (4 waves / SIMD)
+// Measured on MI355X (profiles/r01_gemm_*.txt): a 128^2 tile needs 32 KiB of LDS fill per 512 MFMA cycles,
+// i.e. the whole LDS write rate of a CU, so it saturates at ~45 % of the MFMA peak whatever the pipeline
+// depth; the 256^2 tile halves the fill per FLOP and is used whenever it still yields enough workgroups.
+// Staging: bounds-checked LDS-DMA (buffer_load ... lds, 16 B / lane, out-of-range rows read as 0, which is
+// what zero-pads ragged M / N / K) into a double buffer, the swizzle lives on the per-lane GLOBAL source
+// address and on the read address (cdna guide rule 21).  The 128^2 NN / TN kernels stage through registers
+// instead (loads of two K-tiles in flight, ds_write_b128 after the MFMAs), which measured faster there.
+// MFMA operands are swapped (D = B-frag x A-frag) so that every lane owns 4 consecutive output columns of
+// one output row: 8-byte bf16 / 16-byte fp32 stores.
 //
 // Replaces every nn.Linear forward/backward of volta/encoders.py and volta/embeddings.py
-// (see include/volta_hip.h for the site list).
+// (site list in include/volta_hip.h).
 #include "common.h"
 #include "../../include/volta_hip.h"
 #include "util.h"
 
 namespace vk {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int GEMM_THREADS = 256;
-constexpr int TILE_BYTES = 128 * 64 * 2;          // one operand tile, either orientation
-constexpr int STAGE_BYTES = 2 * TILE_BYTES;
-constexpr int GEMM_LDS = 2 * STAGE_BYTES;         // 64 KiB -> 2 workgroups / CU
+constexpr int BK = 64;
+template <int WM, int WN> struct Geo {
+    static constexpr int THREADS = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
+    static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
+};
 
 struct KProb {
     const char* A; const char* B; char* C; char* C2; const float* bias; const char* R; float* bias_grad;
@@ -33,29 +42,43 @@ struct KGroup {
     KProb p[VK_GEMM_MAX_GROUP];
 };
 
-// XOR applied to the 16-byte chunk index of a row of the transposed ([k][128 cols], 256-B rows) image
+// XOR applied to the 16-byte chunk index of a row of a transposed ([k][cols]) image (low 4 bits only)
 __device__ __forceinline__ int tswz(int row) { return ((row & 3) << 1) ^ (((row >> 3) & 1) << 3); }
 
-// Stage one 16 KiB operand tile.  T=false: image [128 rows][64 k] (128-B rows), element (row0+r, col0+c).
-// T=true: image [64 k][128 cols] (256-B rows), element (row0+r, col0+c) with row0 = k0.
-template <bool T>
-__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, uint32_t lds_tile, int ld, int row0, int col0,
-                                           int tid) {
+// Stage one operand tile of EXT rows (T=false: image [EXT][64 k], 128-B rows) or EXT columns (T=true: image
+// [64 k][EXT], 2*EXT-byte rows) with all THREADS threads; 16-byte chunks, linear LDS image.
+template <bool T, int EXT, int THREADS>
+__device__ __forceinline__ void stage_tile(__amdgpu_buffer_rsrc_t rs, uint32_t lds_tile, int ld, int row0, int col0, int tid) {
+    constexpr int NP = EXT * 8 / THREADS;          // pieces per thread
+    constexpr int CPR = T ? EXT / 8 : 8;           // 16-byte chunks per image row
     const int wave = tid >> 6;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int r, cl;
-        if (!T) {
-            r = i * 32 + (tid >> 3);
-            cl = (tid & 7) ^ (r & 7);
-        } else {
-            r = i * 16 + (tid >> 4);
-            cl = (tid & 15) ^ tswz(r);
-        }
-        uint32_t voff = ((uint32_t)(row0 + r) * (uint32_t)ld + (uint32_t)(col0 + cl * 8)) * 2u;
-        uint32_t dst = lds_tile + i * 4096 + wave * 1024;   // wave-uniform; hardware adds lane*16
+    for (int i = 0; i < NP; ++i) {
+        const int lin = i * THREADS + tid;
+        const int r = lin / CPR, cp = lin % CPR;
+        const int cl = T ? (cp ^ tswz(r)) : (cp ^ (r & 7));
+        const uint32_t voff = ((uint32_t)(row0 + r) * (uint32_t)ld + (uint32_t)(col0 + cl * 8)) * 2u;
+        const uint32_t dst = lds_tile + (i * THREADS + wave * 64) * 16;   // wave-uniform; hardware adds lane*16
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (VK_LDS void*)(uintptr_t)dst, 16, voff, 0, 0, 0);
     }
+}
+template <bool T, int EXT, int THREADS>
+__device__ __forceinline__ void stage_load(__amdgpu_buffer_rsrc_t rs, u32x4 (&reg)[EXT * 8 / THREADS], int ld, int row0, int col0, int tid) {
+    constexpr int NP = EXT * 8 / THREADS;
+    constexpr int CPR = T ? EXT / 8 : 8;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        const int lin = i * THREADS + tid;
+        const int r = lin / CPR, cp = lin % CPR;
+        const int cl = T ? (cp ^ tswz(r)) : (cp ^ (r & 7));
+        const uint32_t voff = ((uint32_t)(row0 + r) * (uint32_t)ld + (uint32_t)(col0 + cl * 8)) * 2u;
+        reg[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0);
+    }
+}
+template <int NP, int THREADS>
+__device__ __forceinline__ void stage_store(uint32_t lds_tile, const u32x4 (&reg)[NP], int tid) {
+#pragma unroll
+    for (int i = 0; i < NP; ++i) *(u32x4 VK_LDS*)(uintptr_t)(lds_tile + (i * THREADS + tid) * 16) = reg[i];
 }
 
 // fragment for the 16 rows [r0, r0+16) of a K-contiguous image, k-substep ks (32 wide)
@@ -64,14 +87,15 @@ __device__ __forceinline__ bf16x8 frag_rows(uint32_t tile, int r0, int ks, int l
     const int c = (ks * 4 + (lane >> 4)) ^ (r & 7);
     return *(const bf16x8 VK_LDS*)(uintptr_t)(tile + r * 128 + c * 16);
 }
-// fragment for the 16 columns [c0, c0+16) of a transposed image ([k][128]); k order = natural
+// fragment for the 16 columns [c0, c0+16) of a transposed image ([k][EXT], ROWB bytes per row); natural k order
+template <int ROWB>
 __device__ __forceinline__ bf16x8 frag_cols(uint32_t tile, int c0, int ks, int lane) {
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const int row_a = ks * 32 + g * 8 + q;
     const int chunk = (c0 >> 3) + (p >> 1);
-    const uint32_t a0 = tile + row_a * 256 + ((chunk ^ tswz(row_a)) << 4) + ((p & 1) << 3);
+    const uint32_t a0 = tile + row_a * ROWB + ((chunk ^ tswz(row_a)) << 4) + ((p & 1) << 3);
     const int row_b = row_a + 4;
-    const uint32_t a1 = tile + row_b * 256 + ((chunk ^ tswz(row_b)) << 4) + ((p & 1) << 3);
+    const uint32_t a1 = tile + row_b * ROWB + ((chunk ^ tswz(row_b)) << 4) + ((p & 1) << 3);
     bf16x4 lo = lds_read_tr16(a0);
     bf16x4 hi = lds_read_tr16(a1);
     bf16x8 r;
@@ -80,12 +104,14 @@ __device__ __forceinline__ bf16x8 frag_cols(uint32_t tile, int c0, int ks, int l
     return r;
 }
 
-template <bool AT, bool BT, int EPI>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const KGroup g) {
+template <bool AT, bool BT, int EPI, int WM, int WN, bool REGSTAGE>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const KGroup g) {
+    using G = Geo<WM, WN>;
+    constexpr int THREADS = G::THREADS, BM = G::BM, BN = G::BN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(VK_LDS char*)smem;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
 
     int pi = 0;
 #pragma unroll
@@ -103,14 +129,11 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const KGroup g) {
     }
     if (m0 >= M) return;
 
-    // buffer extents: last valid row + valid row length
-    const int a_rows = AT ? K : M, a_cols = AT ? P.M : K;
-    const int b_rows = BT ? K : P.N, b_cols = BT ? P.N : K;
-    const __amdgpu_buffer_rsrc_t rsA =
-        make_rsrc(P.A, a_rows > 0 ? (uint32_t)(((uint32_t)(a_rows - 1) * P.lda + (AT ? P.lda : a_cols)) * 2u) : 0u);
-    const __amdgpu_buffer_rsrc_t rsB =
-        make_rsrc(P.B, b_rows > 0 ? (uint32_t)(((uint32_t)(b_rows - 1) * P.ldb + (BT ? P.ldb : b_cols)) * 2u) : 0u);
-    (void)a_cols; (void)b_cols;
+    // buffer extents: last valid row + valid row length (everything beyond reads as zero)
+    const int a_rows = AT ? K : M, a_cols = AT ? P.lda : K;
+    const int b_rows = BT ? K : P.N, b_cols = BT ? P.ldb : K;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(P.A, a_rows > 0 ? (uint32_t)(((uint32_t)(a_rows - 1) * P.lda + a_cols) * 2u) : 0u);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(P.B, b_rows > 0 ? (uint32_t)(((uint32_t)(b_rows - 1) * P.ldb + b_cols) * 2u) : 0u);
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -126,28 +149,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const KGroup g) {
     for (int i = 0; i < 8; ++i) ones[i] = (short)0x3F80;
 
     const int nk = (K + BK - 1) / BK;
-    auto stage = [&](int buf, int kt) {
-        const uint32_t ta = lds0 + buf * STAGE_BYTES, tb = ta + TILE_BYTES;
-        if (AT) stage_tile<true>(rsA, ta, P.lda, kt * BK, m0, tid);
-        else    stage_tile<false>(rsA, ta, P.lda, m0, kt * BK, tid);
-        if (BT) stage_tile<true>(rsB, tb, P.ldb, kt * BK, n0, tid);
-        else    stage_tile<false>(rsB, tb, P.ldb, n0, kt * BK, tid);
-    };
-
-    if (nk > 0) stage(0, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) stage(cur ^ 1, kt + 1);
-        const uint32_t ta = lds0 + cur * STAGE_BYTES, tb = ta + TILE_BYTES;
+    auto compute = [&](int cur) {
+        const uint32_t ta = lds0 + cur * G::STAGE, tb = ta + G::A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8 a[4], b[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-                a[i] = AT ? frag_cols(ta, wm * 64 + i * 16, ks, lane) : frag_rows(ta, wm * 64 + i * 16, ks, lane);
-                b[i] = BT ? frag_cols(tb, wn * 64 + i * 16, ks, lane) : frag_rows(tb, wn * 64 + i * 16, ks, lane);
+                a[i] = AT ? frag_cols<BM * 2>(ta, wm * 64 + i * 16, ks, lane) : frag_rows(ta, wm * 64 + i * 16, ks, lane);
+                b[i] = BT ? frag_cols<BN * 2>(tb, wn * 64 + i * 16, ks, lane) : frag_rows(tb, wn * 64 + i * 16, ks, lane);
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
@@ -159,15 +169,67 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const KGroup g) {
                 for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i], accb[i], 0, 0, 0);
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+
+    if constexpr (REGSTAGE) {
+        // register-staged, prefetch distance 2: tile kt is multiplied out of LDS while tile kt+1 waits in one register
+        // set (written to the other LDS buffer after the MFMAs) and the loads of tile kt+2 are issued into the second.
+        constexpr int NPA = BM * 8 / THREADS, NPB = BN * 8 / THREADS;
+        u32x4 ra0[NPA], rb0[NPB], ra1[NPA], rb1[NPB];
+#define VK_GLOAD(RA, RB, KT)                                                                               \
+        do {                                                                                               \
+            if (AT) stage_load<true, BM, THREADS>(rsA, RA, P.lda, (KT) * BK, m0, tid);                      \
+            else stage_load<false, BM, THREADS>(rsA, RA, P.lda, m0, (KT) * BK, tid);                       \
+            if (BT) stage_load<true, BN, THREADS>(rsB, RB, P.ldb, (KT) * BK, n0, tid);                      \
+            else stage_load<false, BN, THREADS>(rsB, RB, P.ldb, n0, (KT) * BK, tid);                       \
+        } while (0)
+#define VK_LSTORE(RA, RB, BUF)                                                                             \
+        do {                                                                                               \
+            stage_store<NPA, THREADS>(lds0 + (BUF) * G::STAGE, RA, tid);                                   \
+            stage_store<NPB, THREADS>(lds0 + (BUF) * G::STAGE + G::A_BYTES, RB, tid);                      \
+        } while (0)
+        if (nk > 0) VK_GLOAD(ra0, rb0, 0);
+        if (nk > 1) VK_GLOAD(ra1, rb1, 1);
+        if (nk > 0) VK_LSTORE(ra0, rb0, 0);
         __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            if (kt + 2 < nk) VK_GLOAD(ra0, rb0, kt + 2);
+            compute(0);
+            if (kt + 1 < nk) VK_LSTORE(ra1, rb1, 1);
+            __syncthreads();
+            if (kt + 1 < nk) {
+                if (kt + 3 < nk) VK_GLOAD(ra1, rb1, kt + 3);
+                compute(1);
+                if (kt + 2 < nk) VK_LSTORE(ra0, rb0, 0);
+                __syncthreads();
+            }
+        }
+#undef VK_GLOAD
+#undef VK_LSTORE
+    } else {
+        // LDS-DMA double buffer: the DMA of tile kt+1 is issued right after the barrier that retires tile kt-1's reads
+        auto stage = [&](int buf, int kt) {
+            const uint32_t ta = lds0 + buf * G::STAGE, tb = ta + G::A_BYTES;
+            if (AT) stage_tile<true, BM, THREADS>(rsA, ta, P.lda, kt * BK, m0, tid);
+            else    stage_tile<false, BM, THREADS>(rsA, ta, P.lda, m0, kt * BK, tid);
+            if (BT) stage_tile<true, BN, THREADS>(rsB, tb, P.ldb, kt * BK, n0, tid);
+            else    stage_tile<false, BN, THREADS>(rsB, tb, P.ldb, n0, kt * BK, tid);
+        };
+        if (nk > 0) stage(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();          // tile kt landed for every wave; everyone is done reading tile kt-1
+            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+            compute(kt & 1);
+        }
     }
 
     // ---- epilogue: lane owns row m = ...+(lane&15), columns n..n+3 with n = ...+4*(lane>>4) ----
     const int gq = lane >> 4, lr = lane & 15;
     const int Mout = AT ? P.M : M;     // TN: M is the output row count and is never dynamic
     const int N = P.N;
-    const int nlim = ((EPI == VK_EPI_F32 || EPI == VK_EPI_F32_ACC) && P.n_store > N) ? P.n_store : N;
+    constexpr bool F32OUT = (EPI == VK_EPI_F32 || EPI == VK_EPI_F32_ACC);
+    const int nlim = (F32OUT && P.n_store > N) ? P.n_store : N;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + wm * 64 + i * 16 + lr;
@@ -183,7 +245,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const KGroup g) {
             }
             const size_t off = (size_t)m * P.ldc + n;
             const bool full = (n + 3 < nlim);
-            if (EPI == VK_EPI_F32 || EPI == VK_EPI_F32_ACC) {
+            if (F32OUT) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (n + r >= N) v[r] = 0.f;
                 float* c = (float*)P.C + off;
@@ -211,7 +273,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const KGroup g) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 if (EPI == VK_EPI_BF16) o[r] = v[r];
-                else if (EPI == VK_EPI_GELU) { o[r] = gelu_f(v[r]); o2[r] = gelu_grad_f(v[r]); }
+                else if (EPI == VK_EPI_GELU) { gelu_both(v[r], o[r], o2[r]); }
                 else if (EPI == VK_EPI_MULR) o[r] = v[r] * w[r];
                 else if (EPI == VK_EPI_ADDR) o[r] = v[r] + w[r];
                 else o[r] = fmaxf(v[r], 0.f);
@@ -238,14 +300,16 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(const KGroup g) {
     }
 }
 
-template <bool AT, bool BT>
-static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s) {
+template <bool AT, bool BT, int WM, int WN, bool REGSTAGE>
+static int launch_cfg(int epi, const KGroup& g, int total, hipStream_t s) {
+    using G = Geo<WM, WN>;
+    constexpr int LDS = 2 * G::STAGE;
 #define VK_CASE(E)                                                                                        \
     case E: {                                                                                             \
-        auto k = gemm_kernel<AT, BT, E>;                                                                  \
+        auto k = gemm_kernel<AT, BT, E, WM, WN, REGSTAGE>;                                                \
         static bool once = false;                                                                         \
-        if (!once) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS); once = true; } \
-        hipLaunchKernelGGL(k, dim3(total), dim3(GEMM_THREADS), GEMM_LDS, s, g);                           \
+        if (!once) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; } \
+        hipLaunchKernelGGL(k, dim3(total), dim3(G::THREADS), LDS, s, g);                                  \
         break;                                                                                            \
     }
     switch (epi) {
@@ -256,40 +320,78 @@ static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s) {
     return check_launch("vk_gemm_grouped");
 }
 
+static int g_tile_override = 0;       // tuning hook: 0 = heuristic, 128 / 192 / 256 = force 128x128 / 256x128 / 256x256
+static int g_regstage_override = -1;  // -1 = heuristic, 0 / 1 = force LDS-DMA / register staging (128^2 only)
+
+static int total_tiles(const vk_gemm_problem* probs, int nprob, int epilogue, int bm, int bn) {
+    int total = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const vk_gemm_problem& q = probs[i];
+        const bool f32 = epilogue == VK_EPI_F32 || epilogue == VK_EPI_F32_ACC;
+        const int ncols = (f32 && q.n_store > q.N) ? q.n_store : q.N;
+        total += ((q.M + bm - 1) / bm) * ((ncols + bn - 1) / bn);
+    }
+    return total;
+}
+
 }  // namespace vk
 
 extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, vk_stream_t stream) {
     using namespace vk;
     if (nprob < 1 || nprob > VK_GEMM_MAX_GROUP) return set_error("vk_gemm_grouped: nprob %d out of range", nprob);
-    KGroup g;
-    g.nprob = nprob;
-    int total = 0;
+    const bool f32out = epilogue == VK_EPI_F32 || epilogue == VK_EPI_F32_ACC;
     for (int i = 0; i < nprob; ++i) {
         const vk_gemm_problem& q = probs[i];
         if (q.M < 0 || q.N <= 0 || q.K < 0) return set_error("vk_gemm_grouped: bad shape %d %d %d", q.M, q.N, q.K);
         if ((q.lda & 7) || (q.ldb & 7)) return set_error("vk_gemm_grouped: lda/ldb must be multiples of 8 (got %d %d)", q.lda, q.ldb);
         if (((uintptr_t)q.A & 15) || ((uintptr_t)q.B & 15) || ((uintptr_t)q.C & 15)) return set_error("vk_gemm_grouped: operands must be 16-byte aligned");
-        if (epilogue != VK_EPI_F32 && epilogue != VK_EPI_F32_ACC && (q.ldc & 3)) return set_error("vk_gemm_grouped: ldc must be a multiple of 4");
+        if (!f32out && (q.ldc & 3)) return set_error("vk_gemm_grouped: ldc must be a multiple of 4");
         if (layout != VK_TN && (q.K % 64) != 0 && q.lda < ((q.K + 63) / 64) * 64)
             return set_error("vk_gemm_grouped: K=%d needs lda padded to a multiple of 64", q.K);
         if (layout != VK_TN && q.bias_grad) return set_error("vk_gemm_grouped: bias_grad is a TN (wgrad) feature");
         if ((epilogue == VK_EPI_MULR || epilogue == VK_EPI_ADDR) && !q.R) return set_error("vk_gemm_grouped: R missing");
         if (epilogue == VK_EPI_GELU && !q.C2) return set_error("vk_gemm_grouped: C2 missing");
+    }
+    // Tile choice: the largest of 256x256 / 256x128 / 128x128 that still yields >= 160 workgroups (256 CUs).
+    // `edge` encodes the geometry: 256 -> 256x256, 192 -> 256x128, 128 -> 128x128.
+    int edge = g_tile_override;
+    if (edge == 0) {
+        edge = total_tiles(probs, nprob, epilogue, 256, 256) >= 160 ? 256 : 128;   // 256x128 never won (profiles/r01_gemm_tiles.txt)
+    }
+    const int bm = edge == 128 ? 128 : 256, bn = edge == 256 ? 256 : 128;
+    KGroup g;
+    g.nprob = nprob;
+    int total = 0;
+    for (int i = 0; i < nprob; ++i) {
+        const vk_gemm_problem& q = probs[i];
         KProb& k = g.p[i];
         k.A = (const char*)q.A; k.B = (const char*)q.B; k.C = (char*)q.C; k.C2 = (char*)q.C2; k.bias = q.bias;
         k.R = (const char*)q.R; k.bias_grad = q.bias_grad; k.dyn = q.dyn;
         k.M = q.M; k.N = q.N; k.K = q.K; k.lda = q.lda; k.ldb = q.ldb; k.ldc = q.ldc; k.ldr = q.ldr; k.n_store = q.n_store;
-        const int ncols = ((epilogue == VK_EPI_F32 || epilogue == VK_EPI_F32_ACC) && q.n_store > q.N) ? q.n_store : q.N;
-        k.tiles_n = (ncols + BN - 1) / BN;
+        const int ncols = (f32out && q.n_store > q.N) ? q.n_store : q.N;
+        k.tiles_n = (ncols + bn - 1) / bn;
         k.tile_start = total;
-        total += ((q.M + BM - 1) / BM) * k.tiles_n;
+        total += ((q.M + bm - 1) / bm) * k.tiles_n;
     }
     if (total == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    switch (layout) {
-        case VK_NT: return launch_layout<false, false>(epilogue, g, total, s);
-        case VK_NN: return launch_layout<false, true>(epilogue, g, total, s);
-        case VK_TN: return launch_layout<true, true>(epilogue, g, total, s);
+    if (edge == 256) {
+        if (layout == VK_NT) return launch_cfg<false, false, 4, 4, false>(epilogue, g, total, s);
+        if (layout == VK_NN) return launch_cfg<false, true, 4, 4, false>(epilogue, g, total, s);
+        if (layout == VK_TN) return launch_cfg<true, true, 4, 4, false>(epilogue, g, total, s);
+    } else if (edge == 192) {
+        if (layout == VK_NT) return launch_cfg<false, false, 4, 2, false>(epilogue, g, total, s);
+        if (layout == VK_NN) return launch_cfg<false, true, 4, 2, false>(epilogue, g, total, s);
+        if (layout == VK_TN) return launch_cfg<true, true, 4, 2, false>(epilogue, g, total, s);
+    } else {
+        const bool reg = g_regstage_override >= 0 ? g_regstage_override != 0 : layout != VK_NT;
+        if (layout == VK_NT) return reg ? launch_cfg<false, false, 2, 2, true>(epilogue, g, total, s) : launch_cfg<false, false, 2, 2, false>(epilogue, g, total, s);
+        if (layout == VK_NN) return reg ? launch_cfg<false, true, 2, 2, true>(epilogue, g, total, s) : launch_cfg<false, true, 2, 2, false>(epilogue, g, total, s);
+        if (layout == VK_TN) return reg ? launch_cfg<true, true, 2, 2, true>(epilogue, g, total, s) : launch_cfg<true, true, 2, 2, false>(epilogue, g, total, s);
     }
     return set_error("vk_gemm_grouped: unknown layout %d", layout);
 }
+
+/* tuning hooks for tools/bench_gemm.py (0 / -1 restore the heuristics) */
+extern "C" void vk_gemm_set_tile(int edge) { vk::g_tile_override = edge; }
+extern "C" void vk_gemm_set_regstage(int v) { vk::g_regstage_override = v; }

@@ -201,13 +201,22 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(vk_ln_bwd_args a) {
     }
 }
 
-__global__ void ln_bwd_finalize_kernel(const float* partial, int nblk, int H, float* dgamma, float* dbeta, int accumulate) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * H) return;
+// column sums of the per-workgroup partial records: 64 columns x 16 row groups per workgroup
+__global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* partial, int nblk, int H, float* dgamma, float* dbeta, int accumulate) {
+    __shared__ float red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int i = blockIdx.x * 64 + tx;
     float s = 0.f;
-    for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * 2 * H + i];
-    float* o = i < H ? dgamma + i : dbeta + (i - H);
-    *o = accumulate ? *o + s : s;
+    if (i < 2 * H)
+        for (int b = ty; b < nblk; b += 16) s += partial[(size_t)b * 2 * H + i];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && i < 2 * H) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s += red[k][tx];
+        float* o = i < H ? dgamma + i : dbeta + (i - H);
+        *o = accumulate ? *o + s : s;
+    }
 }
 
 }  // namespace vk
@@ -245,7 +254,7 @@ extern "C" int vk_ln_bwd(const vk_ln_bwd_args* a, vk_stream_t stream) {
         case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, *a); break;
         default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, *a); break;
     }
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * a->H + 255) / 256), dim3(256), 0, s, a->partial, nblk, a->H,
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * a->H + 63) / 64), dim3(1024), 0, s, a->partial, nblk, a->H,
                        a->dgamma, a->dbeta, a->accumulate);
     return check_launch("vk_ln_bwd");
 }

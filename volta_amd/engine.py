@@ -590,7 +590,6 @@ class StepEngine:
             dctx[m] = self.tmp("dctx%d" % m, (self.st[m].M, H))
             dqkv[m] = self.tmp("dqkv%d" % m, (self.st[m].M, 3 * H))
         self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dd[m], self.W(names[m]["o"] + ".weight"), dctx[m], self.st[m].M, H, H, H, H, H) for m in ms])
-        self._wgrad(b, ms, shared, lambda m: (dd[m], ctx[m], self.G(names[m]["o"] + ".weight"), self.G(names[m]["o"] + ".bias"), H, H, H, H))
         ab = L.AttnBwdArgs()
         for m in ms:
             if not (gate[0][m] or gate[1][m]):       # K/V of this modality unused: their gradient is zero
@@ -601,7 +600,9 @@ class StepEngine:
         self.k(ab)
         b.append((L.OP_ATTN_BWD, 0, 0, 0, aa, ab, None))
         self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dqkv[m], wqkv(m, "shadow"), dxn[m], self.st[m].M, H, 3 * H, 3 * H, H, H, R=dz[m], ldr=H) for m in ms])
-        self._wgrad(b, ms, shared, lambda m: (dqkv[m], x_in[m], wqkv(m, "grad"), bqkv(m, "grad"), 3 * H, H, 3 * H, H))
+        # all weight gradients of the sub-layer in ONE grouped launch (more workgroups per CU)
+        self._wgrad(b, ms, shared, [lambda m: (dd[m], ctx[m], self.G(names[m]["o"] + ".weight"), self.G(names[m]["o"] + ".bias"), H, H, H, H),
+                                    lambda m: (dqkv[m], x_in[m], wqkv(m, "grad"), bqkv(m, "grad"), 3 * H, H, 3 * H, H)])
         return b
 
     def _ffn_sublayer(self, n):
@@ -636,22 +637,25 @@ class StepEngine:
                                                               dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc), None, None))
             du[m] = self.tmp("du%d" % m, (self.st[m].M, I))
         self.gemm(b, L.NN, L.EPI_MULR, [self.prob(dd[m], self.W(names[m]["down"] + ".weight"), du[m], self.st[m].M, I, H, H, I, I, R=gp[m], ldr=I) for m in ms])
-        self._wgrad(b, ms, shared, lambda m: (dd[m], h[m], self.G(names[m]["down"] + ".weight"), self.G(names[m]["down"] + ".bias"), H, I, H, I))
         self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(du[m], self.W(names[m]["up"] + ".weight"), dxn[m], self.st[m].M, H, I, I, H, H, R=dz[m], ldr=H) for m in ms])
-        self._wgrad(b, ms, shared, lambda m: (du[m], x_in[m], self.G(names[m]["up"] + ".weight"), self.G(names[m]["up"] + ".bias"), I, H, I, H))
+        self._wgrad(b, ms, shared, [lambda m: (dd[m], h[m], self.G(names[m]["down"] + ".weight"), self.G(names[m]["down"] + ".bias"), H, I, H, I),
+                                    lambda m: (du[m], x_in[m], self.G(names[m]["up"] + ".weight"), self.G(names[m]["up"] + ".bias"), I, H, I, H)])
         return b
 
-    def _wgrad(self, b, ms, shared, spec):
-        """dW[Mo, No] = dY^T X (+ bias grad); weights shared by both modalities: second launch accumulates."""
-        probs = []
+    def _wgrad(self, b, ms, shared, specs):
+        """dW[Mo, No] = dY^T X (+ bias grad) for every spec and modality in one grouped TN launch; weights shared by
+        both modalities: the first modality's launch overwrites, the second one's accumulates."""
+        per_m = {}
         for m in ms:
-            dY, X, gW, gB, Mo, No, lda, ldb = spec(m)
-            probs.append(self.prob(dY, X, gW, Mo, No, self.st[m].M, lda, ldb, No, bias_grad=gB))
-        if shared and len(probs) == 2:
-            self.gemm(b, L.TN, L.EPI_F32, probs[:1])
-            self.gemm(b, L.TN, L.EPI_F32_ACC, probs[1:])
+            per_m[m] = []
+            for spec in specs:
+                dY, X, gW, gB, Mo, No, lda, ldb = spec(m)
+                per_m[m].append(self.prob(dY, X, gW, Mo, No, self.st[m].M, lda, ldb, No, bias_grad=gB))
+        if shared and len(ms) == 2:
+            self.gemm(b, L.TN, L.EPI_F32, per_m[ms[0]])
+            self.gemm(b, L.TN, L.EPI_F32_ACC, per_m[ms[1]])
         else:
-            self.gemm(b, L.TN, L.EPI_F32, probs)
+            self.gemm(b, L.TN, L.EPI_F32, [p for m in ms for p in per_m[m]])
 
     # ---------------------------------------------------------------- heads + losses
     def _heads(self):
