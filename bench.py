@@ -186,7 +186,7 @@ def main():
             ach = pairs_s / world * gflop / 1e3            # per-GPU TFLOP/s
             out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
                                "traffic": None, "scope": "whole step: pairs/s x %.3f GFLOP/pair (reference-graph matmul FLOPs, BASELINE.md)" % gflop}
-        if not a.no_kernel_timing:
+        if not a.no_kernel_timing and world == 1:      # extra profiled steps would desynchronise the ranks' collectives
             eng = model._last[0]
             eng.fwd.enable_timing(True)
             eng.bwd.enable_timing(True)

@@ -39,6 +39,7 @@ struct KProb {
 };
 struct KGroup {
     int32_t nprob;
+    int32_t stagger;   // 1: half of the waves of each SIMD issue their LDS-DMA after the first MFMA half-step
     KProb p[VK_GEMM_MAX_GROUP];
 };
 
@@ -113,12 +114,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const KGroup g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
+    // XCD-aware tile order (cdna guide T1): workgroups are dealt round-robin over the 8 XCDs, so give XCD x the
+    // contiguous chunk x of the tile list -- neighbouring tiles (same A row panel) then share one L2.  Bijective for
+    // any grid size; placement only affects speed.
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+    }
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < VK_GEMM_MAX_GROUP; ++i)
-        if (i < g.nprob && (int)blockIdx.x >= g.p[i].tile_start) pi = i;
+        if (i < g.nprob && bid >= g.p[i].tile_start) pi = i;
     const KProb& P = g.p[pi];
-    const int t = blockIdx.x - P.tile_start;
+    const int t = bid - P.tile_start;
     const int tm = t / P.tiles_n, tn = t - tm * P.tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -149,10 +158,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const KGroup g) {
     for (int i = 0; i < 8; ++i) ones[i] = (short)0x3F80;
 
     const int nk = (K + BK - 1) / BK;
-    auto compute = [&](int cur) {
+    auto compute_ks = [&](int cur, int ks) {
         const uint32_t ta = lds0 + cur * G::STAGE, tb = ta + G::A_BYTES;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
+        {
             bf16x8 a[4], b[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -170,6 +178,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const KGroup g) {
             }
         }
     };
+    auto compute = [&](int cur) { compute_ks(cur, 0); compute_ks(cur, 1); };
 
     if constexpr (REGSTAGE) {
         // register-staged, prefetch distance 2: tile kt is multiplied out of LDS while tile kt+1 waits in one register
@@ -216,11 +225,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const KGroup g) {
             else    stage_tile<false, BN, THREADS>(rsB, tb, P.ldb, n0, kt * BK, tid);
         };
         if (nk > 0) stage(0, 0);
+        // Waves 4..7 and 12..15 of a 16-wave workgroup share their SIMDs with waves 0..3 / 8..11: they issue the DMA of
+        // the next tile after their first 16 MFMAs instead of before them, so that on every SIMD two waves feed the
+        // matrix pipe while the other two pay the LDS-DMA issue cost (60-185 cycles per piece).
+        const bool late = g.stagger && (WM * WN > 4) && ((__builtin_amdgcn_readfirstlane(wave) >> 2) & 1);
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();          // tile kt landed for every wave; everyone is done reading tile kt-1
-            if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-            compute(kt & 1);
+            if (!late && kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+            compute_ks(kt & 1, 0);
+            if (late && kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+            compute_ks(kt & 1, 1);
         }
     }
 
@@ -321,6 +336,7 @@ static int launch_cfg(int epi, const KGroup& g, int total, hipStream_t s) {
 }
 
 static int g_tile_override = 0;       // tuning hook: 0 = heuristic, 128 / 192 / 256 = force 128x128 / 256x128 / 256x256
+static int g_stagger = 1;
 static int g_regstage_override = -1;  // -1 = heuristic, 0 / 1 = force LDS-DMA / register staging (128^2 only)
 
 static int total_tiles(const vk_gemm_problem* probs, int nprob, int epilogue, int bm, int bn) {
@@ -361,6 +377,7 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
     const int bm = edge == 128 ? 128 : 256, bn = edge == 256 ? 256 : 128;
     KGroup g;
     g.nprob = nprob;
+    g.stagger = g_stagger;
     int total = 0;
     for (int i = 0; i < nprob; ++i) {
         const vk_gemm_problem& q = probs[i];
@@ -395,3 +412,4 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
 /* tuning hooks for tools/bench_gemm.py (0 / -1 restore the heuristics) */
 extern "C" void vk_gemm_set_tile(int edge) { vk::g_tile_override = edge; }
 extern "C" void vk_gemm_set_regstage(int v) { vk::g_regstage_override = v; }
+extern "C" void vk_gemm_set_stagger(int v) { vk::g_stagger = v; }

@@ -12,7 +12,7 @@ namespace vk {
 
 constexpr float LN_EPS = 1e-12f;
 constexpr int LN_THREADS = 256;
-constexpr int LN_BWD_ROWS = 32;     // rows per workgroup in the backward (8 per wave)
+constexpr int LN_BWD_ROWS = 8;      // rows per workgroup in the backward (2 per wave): >= 640 workgroups at B = 256
 
 // Philox row of `row` under the two-segment mapping of vk_ln_args.seg (see include/volta_hip.h)
 __device__ __forceinline__ uint32_t drop_row(const vk_drop_rows (&seg)[2], int split, int row, uint32_t& site) {
