@@ -215,6 +215,19 @@ int vk_loc_linear_bwd(const void* dz, const float* loc, float* partial, float* d
 int vk_add_dropout(const void* a, const void* b, void* y, int M, int H, float scale, vk_dropout drop, int backward, vk_stream_t s);
 /* out[c] (+)= sum_m src[m][c]; partial: fp32 [vk_rows32(M), H]. */
 int vk_colsum_bf16(const void* src, float* partial, float* out, int M, int H, int accumulate, vk_stream_t s);
+/* VL-BERT region input (volta/embeddings.py:102-124 coordinate_embeddings, :243-251): builds the bf16 row
+ * [sin|cos box embedding (4 x 2*dim) | appearance feature (F)] of the obj_downsample input with dropout;
+ * all-zero feature rows take mask_emb (object_mask_visual_embedding) and are flagged in zero_flag[M]. */
+int vk_vlbert_prep_fwd(const float* loc, int nloc, const float* feat, const float* mask_emb, void* out, int32_t* zero_flag,
+                       int M, int F, int dim, vk_dropout drop, vk_stream_t s);
+/* d(mask_emb)[f] = sum over flagged rows of dropout-masked dx[row][col0 + f]; partial: fp32 [vk_rows32(M), F]. */
+int vk_vlbert_maskgrad(const void* dx, int ldx, int col0, const int32_t* zero_flag, float* partial, float* out, int M, int F,
+                       vk_dropout drop, vk_stream_t s);
+/* out[b] = sum of the T consecutive rows of sample b (gradient of a per-sample broadcast), bf16 [B, H]. */
+int vk_rowgroup_sum_bf16(const void* in, void* out, int B, int T, int H, vk_stream_t s);
+/* out = dy where y > 0 else 0 (ReLU backward from the kept output), n bf16 elements. */
+int vk_relu_bwd_bf16(const void* dy, const void* y, void* out, int64_t n, vk_stream_t s);
+int vk_copy_async(void* dst, const void* src, int64_t bytes, vk_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * Heads and losses, evaluated on labelled rows only.  Replaces BertPreTrainingHeads + the loss code of
@@ -305,7 +318,8 @@ enum {
 };
 enum {
     VK_FN_CAST = 1, VK_FN_MEMSET, VK_FN_LOC_FWD, VK_FN_LOC_BWD, VK_FN_ADD_DROPOUT, VK_FN_COLSUM, VK_FN_SELECT,
-    VK_FN_GATHER, VK_FN_SCATTER_ADD, VK_FN_LOSS_FINAL, VK_FN_POOL_FWD, VK_FN_POOL_BWD, VK_FN_MASK_PREP, VK_FN_MUL
+    VK_FN_GATHER, VK_FN_SCATTER_ADD, VK_FN_LOSS_FINAL, VK_FN_POOL_FWD, VK_FN_POOL_BWD, VK_FN_MASK_PREP, VK_FN_MUL,
+    VK_FN_VLBERT_PREP, VK_FN_VLBERT_MASKGRAD, VK_FN_ROWGROUP_SUM, VK_FN_RELU_BWD, VK_FN_COPY
 };
 typedef struct vk_generic_args {   /* positional arguments of the small entry points, see executor.cpp */
     int32_t fn;

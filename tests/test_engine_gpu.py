@@ -20,6 +20,7 @@ CONFIGS = {
                    vt_attn_sublayers=[4], shared_sublayers=[4], t_ff_sublayers=[1, 3, 6], v_ff_sublayers=[1, 6]),
     "uniter": dict(BASE, image_embeddings="uniter", **SINGLE),
     "visualbert": dict(BASE, image_embeddings="visualbert", **SINGLE),
+    "vlbert": dict(BASE, image_embeddings="vl-bert", type_vocab_size=3, image_head_ln=False, v_coordinate_embeddings_dim=32, **SINGLE),
     "gated": dict(BASE, image_embeddings="vilbert", tt_attn_sublayers=[0], tv_attn_sublayers=[0], vt_attn_sublayers=[0],
                   vv_attn_sublayers=[0], t_ff_sublayers=[1], v_ff_sublayers=[1]),
 }

@@ -96,7 +96,8 @@ class Op(C.Structure):
 (OP_GEMM, OP_LN_FWD, OP_LN_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_EMBED_FWD, OP_EMBED_BWD, OP_XENT_FWD, OP_XENT_BWD,
  OP_KL_FWD, OP_KL_BWD, OP_GENERIC) = range(1, 13)
 (FN_CAST, FN_MEMSET, FN_LOC_FWD, FN_LOC_BWD, FN_ADD_DROPOUT, FN_COLSUM, FN_SELECT, FN_GATHER, FN_SCATTER_ADD,
- FN_LOSS_FINAL, FN_POOL_FWD, FN_POOL_BWD, FN_MASK_PREP, FN_MUL) = range(1, 15)
+ FN_LOSS_FINAL, FN_POOL_FWD, FN_POOL_BWD, FN_MASK_PREP, FN_MUL, FN_VLBERT_PREP, FN_VLBERT_MASKGRAD, FN_ROWGROUP_SUM,
+ FN_RELU_BWD, FN_COPY) = range(1, 20)
 
 
 class AttnArgs(C.Structure):
@@ -138,6 +139,11 @@ _sig("vk_loc_linear_fwd", C.c_int, c_p, c_p, c_p, c_p, C.c_int, C.c_int, C.c_int
 _sig("vk_loc_linear_bwd", C.c_int, c_p, c_p, c_p, c_p, c_p, C.c_int, C.c_int, C.c_int, c_p)
 _sig("vk_add_dropout", C.c_int, c_p, c_p, c_p, C.c_int, C.c_int, C.c_float, Dropout, C.c_int, c_p)
 _sig("vk_colsum_bf16", C.c_int, c_p, c_p, c_p, C.c_int, C.c_int, C.c_int, c_p)
+_sig("vk_vlbert_prep_fwd", C.c_int, c_p, C.c_int, c_p, c_p, c_p, c_p, C.c_int, C.c_int, C.c_int, Dropout, c_p)
+_sig("vk_vlbert_maskgrad", C.c_int, c_p, C.c_int, C.c_int, c_p, c_p, c_p, C.c_int, C.c_int, Dropout, c_p)
+_sig("vk_rowgroup_sum_bf16", C.c_int, c_p, c_p, C.c_int, C.c_int, C.c_int, c_p)
+_sig("vk_relu_bwd_bf16", C.c_int, c_p, c_p, c_p, C.c_int64, c_p)
+_sig("vk_copy_async", C.c_int, c_p, c_p, C.c_int64, c_p)
 _sig("vk_select_rows", C.c_int, c_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_p, c_p, c_p, c_p)
 _sig("vk_gather_rows", C.c_int, c_p, c_p, c_p, c_p, C.c_int, C.c_int, c_p)
 _sig("vk_scatter_rows_add", C.c_int, c_p, c_p, c_p, c_p, C.c_int, C.c_int, c_p)
@@ -161,7 +167,8 @@ _sig("vk_run_ops_timed", C.c_int, C.POINTER(Op), C.c_int, c_p, C.POINTER(C.c_flo
 EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_cast_f32_bf16", "vk_gemm_grouped",
            "vk_ln_fwd", "vk_ln_bwd_partial_rows", "vk_ln_bwd", "vk_gated_attn_fwd", "vk_gated_attn_bwd",
            "vk_embed_sum_fwd", "vk_embed_sum_bwd", "vk_rows32", "vk_loc_linear_fwd", "vk_loc_linear_bwd",
-           "vk_add_dropout", "vk_colsum_bf16", "vk_select_rows", "vk_gather_rows", "vk_scatter_rows_add", "vk_xent_fwd",
+           "vk_add_dropout", "vk_colsum_bf16", "vk_vlbert_prep_fwd", "vk_vlbert_maskgrad", "vk_rowgroup_sum_bf16",
+           "vk_relu_bwd_bf16", "vk_copy_async", "vk_select_rows", "vk_gather_rows", "vk_scatter_rows_add", "vk_xent_fwd",
            "vk_xent_bwd", "vk_kl_fwd", "vk_kl_bwd", "vk_loss_finalize", "vk_pool_mul_fwd", "vk_pool_mul_bwd",
            "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_adamw_step",
            "vk_axpy_f32", "vk_memset_async", "vk_run_ops", "vk_run_ops_timed"]

@@ -259,9 +259,164 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* part
     out[c] = accumulate ? out[c] + s : s;
 }
 
+// ---- VL-BERT region input (volta/embeddings.py:102-124, 243-251): one wave per region row builds the bf16 row
+// [ sin/cos coordinate embedding (4 x 2*dim) | appearance feature (F) ] of the 2F-wide obj_downsample input:
+//   * all-zero feature rows (masked regions) take the learned object_mask_visual_embedding instead (flag saved)
+//   * box (x1,y1,x2,y2) -> (xc, yc, w, h) * 100, divided by 1000^(i/dim), sin | cos per coordinate
+//   * dropout over the whole row (obj_downsample[0])
+__global__ __launch_bounds__(256) void vlbert_prep_kernel(const float* loc, int nloc, const float* feat, const float* mask_emb, uint16_t* out,
+                                                          int32_t* zero_flag, int M, int F, int dim, vk_dropout dc) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* f = feat + (size_t)row * F;
+    bool nz = false;
+    for (int c = lane * 4; c < F; c += 256) {
+        const f32x4 v = *(const f32x4*)(f + c);
+        nz |= (v[0] != 0.f) | (v[1] != 0.f) | (v[2] != 0.f) | (v[3] != 0.f);
+    }
+    const bool zero_row = __ballot(nz) == 0ull;
+    if (lane == 0) zero_flag[row] = zero_row ? 1 : 0;
+    const float x1 = loc[(size_t)row * nloc + 0], y1 = loc[(size_t)row * nloc + 1], x2 = loc[(size_t)row * nloc + 2], y2 = loc[(size_t)row * nloc + 3];
+    const float pos[4] = {(x1 + x2) / 2 * 100, (y1 + y2) / 2 * 100, (x2 - x1) * 100, (y2 - y1) * 100};
+    const int W = 8 * dim + F;
+    const bool don = dc.threshold != 0;
+    const uint64_t seed = don ? *dc.seed : 0;
+    uint16_t* o = out + (size_t)row * W;
+    for (int c = lane * 4; c < W; c += 256) {
+        float v[4];
+        if (c < 8 * dim) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int idx = c + r, coord = idx / (2 * dim), j = idx % (2 * dim), i = j < dim ? j : j - dim;
+                const float ang = pos[coord] / powf(1000.0f, (float)i / (float)dim);
+                v[r] = j < dim ? sinf(ang) : cosf(ang);
+            }
+        } else {
+            const int fc = c - 8 * dim;
+            const f32x4 fv = zero_row ? *(const f32x4*)(mask_emb + fc) : *(const f32x4*)(f + fc);
+            v[0] = fv[0]; v[1] = fv[1]; v[2] = fv[2]; v[3] = fv[3];
+        }
+        if (don) {
+            const u32x4 w = philox4((uint32_t)(c >> 2), (uint32_t)row, dc.site, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = (w[r] >= dc.threshold) ? v[r] * dc.scale : 0.f;
+        }
+        st4(o + c, v);
+    }
+}
+
+// gradient of the mask embedding: partial[blk][f] = sum over the block's flagged rows of keep * dx[row][col0 + f]
+template <int NCH>
+__global__ __launch_bounds__(256) void vlbert_maskgrad_kernel(const uint16_t* dx, int ldx, int col0, const int32_t* zero_flag, float* partial,
+                                                              int M, int F, vk_dropout dc) {
+    __shared__ float red[4][NCH * 256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool don = dc.threshold != 0;
+    const uint64_t seed = don ? *dc.seed : 0;
+    float acc[NCH][4];
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[j][r] = 0.f;
+    for (int it = 0; it < 8; ++it) {
+        const int row = blockIdx.x * 32 + it * 4 + wave;
+        if (row >= M) break;
+        if (!zero_flag[row]) continue;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = j * 256 + lane * 4;
+            if (c < F) {
+                float v[4];
+                ld4(dx + (size_t)row * ldx + col0 + c, v);
+                u32x4 w = {~0u, ~0u, ~0u, ~0u};
+                if (don) w = philox4((uint32_t)((col0 + c) >> 2), (uint32_t)row, dc.site, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[j][r] += (w[r] >= dc.threshold) ? v[r] * dc.scale : 0.f;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NCH; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) red[wave][j * 256 + lane * 4 + r] = acc[j][r];
+    __syncthreads();
+    for (int c = threadIdx.x; c < F; c += 256) partial[(size_t)blockIdx.x * F + c] = red[0][c] + red[1][c] + red[2][c] + red[3][c];
+}
+
+// out[b][c] = sum_{t < T} in[(b*T + t)][c]   (gradient of a per-sample vector broadcast over its T rows)
+__global__ __launch_bounds__(64) void rowgroup_sum_kernel(const uint16_t* in, uint16_t* out, int T, int H) {
+    const int b = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x * 4;
+    if (c >= H) return;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < T; ++t) {
+        float v[4];
+        ld4(in + ((size_t)b * T + t) * H + c, v);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s[r] += v[r];
+    }
+    st4(out + (size_t)b * H + c, s);
+}
+
+// out = dy where y > 0 else 0  (backward of a ReLU whose output y was kept)
+__global__ void relu_bwd_kernel(const uint16_t* dy, const uint16_t* y, uint16_t* out, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
+        const u32x4 g = *(const u32x4*)(dy + i * 8), v = *(const u32x4*)(y + i * 8);
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t lo = (bf2f(v[k] & 0xFFFF) > 0.f) ? (g[k] & 0xFFFFu) : 0u, hi = (bf2f(v[k] >> 16) > 0.f) ? (g[k] & 0xFFFF0000u) : 0u;
+            o[k] = lo | hi;
+        }
+        *(u32x4*)(out + i * 8) = o;
+    }
+}
+
 }  // namespace vk
 
 using namespace vk;
+
+extern "C" int vk_vlbert_prep_fwd(const float* loc, int nloc, const float* feat, const float* mask_emb, void* out, int32_t* zero_flag,
+                                  int M, int F, int dim, vk_dropout drop, vk_stream_t s) {
+    if (F % 4 || (8 * dim) % 4 || nloc < 4) return set_error("vk_vlbert_prep_fwd: F and 8*dim must be multiples of 4, nloc >= 4");
+    if (M <= 0) return 0;
+    hipLaunchKernelGGL(vlbert_prep_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)s, loc, nloc, feat, mask_emb, (uint16_t*)out, zero_flag, M, F, dim, drop);
+    return check_launch("vk_vlbert_prep_fwd");
+}
+
+extern "C" int vk_vlbert_maskgrad(const void* dx, int ldx, int col0, const int32_t* zero_flag, float* partial, float* out, int M, int F,
+                                  vk_dropout drop, vk_stream_t s) {
+    if (F % 4 || F > 2048 || col0 % 4) return set_error("vk_vlbert_maskgrad: F must be a multiple of 4, <= 2048");
+    if (M <= 0) return 0;
+    const int nblk = (M + 31) / 32, nch = (F + 255) / 256;
+    hipStream_t st = (hipStream_t)s;
+    if (nch <= 4) hipLaunchKernelGGL(vlbert_maskgrad_kernel<4>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)dx, ldx, col0, zero_flag, partial, M, F, drop);
+    else hipLaunchKernelGGL(vlbert_maskgrad_kernel<8>, dim3(nblk), dim3(256), 0, st, (const uint16_t*)dx, ldx, col0, zero_flag, partial, M, F, drop);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((F + 63) / 64), dim3(1024), 0, st, partial, nblk, F, out, 0);
+    return check_launch("vk_vlbert_maskgrad");
+}
+
+extern "C" int vk_rowgroup_sum_bf16(const void* in, void* out, int B, int T, int H, vk_stream_t s) {
+    if (H % 4) return set_error("vk_rowgroup_sum_bf16: H %% 4 != 0");
+    if (B <= 0) return 0;
+    hipLaunchKernelGGL(rowgroup_sum_kernel, dim3(B, (H + 255) / 256), dim3(64), 0, (hipStream_t)s, (const uint16_t*)in, (uint16_t*)out, T, H);
+    return check_launch("vk_rowgroup_sum_bf16");
+}
+
+extern "C" int vk_relu_bwd_bf16(const void* dy, const void* y, void* out, int64_t n, vk_stream_t s) {
+    if (n % 8) return set_error("vk_relu_bwd_bf16: n %% 8 != 0");
+    if (n <= 0) return 0;
+    int64_t blocks = (n / 8 + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (const uint16_t*)dy, (const uint16_t*)y, (uint16_t*)out, (size_t)(n / 8));
+    return check_launch("vk_relu_bwd_bf16");
+}
+
+extern "C" int vk_copy_async(void* dst, const void* src, int64_t bytes, vk_stream_t s) {
+    if (bytes <= 0) return 0;
+    hipError_t e = hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToDevice, (hipStream_t)s);
+    if (e != hipSuccess) return set_error("vk_copy_async: %s", hipGetErrorString(e));
+    return 0;
+}
 
 extern "C" int vk_embed_sum_fwd(const vk_embed_args* a, vk_stream_t s) {
     if (a->H % 4) return set_error("vk_embed_sum_fwd: H %% 4 != 0");

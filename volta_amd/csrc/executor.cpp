@@ -74,6 +74,11 @@ static int run_one(const vk_op& o, int i, vk_stream_t s) {
                     case VK_FN_POOL_BWD: rc = vk_pool_mul_bwd(g->p[0], (int)g->n[2], g->p[1], g->p[2], g->p[3], g->p[4], (int)g->n[0], (int)g->n[1], g->drop, s); break;
                     case VK_FN_MASK_PREP: rc = vk_mask_prep((const int64_t*)g->p[0], (float*)g->p[1], (int)g->n[0], s); break;
                     case VK_FN_MUL: rc = vk_mul_bf16(g->p[0], g->p[1], g->p[2], g->n[0], (const int32_t*)g->p[3], (int)g->n[1], s); break;
+                    case VK_FN_VLBERT_PREP: rc = vk_vlbert_prep_fwd((const float*)g->p[0], (int)g->n[3], (const float*)g->p[1], (const float*)g->p[2], g->p[3], (int32_t*)g->p[4], (int)g->n[0], (int)g->n[1], (int)g->n[2], g->drop, s); break;
+                    case VK_FN_VLBERT_MASKGRAD: rc = vk_vlbert_maskgrad(g->p[0], (int)g->n[2], (int)g->n[3], (const int32_t*)g->p[1], (float*)g->p[2], (float*)g->p[3], (int)g->n[0], (int)g->n[1], g->drop, s); break;
+                    case VK_FN_ROWGROUP_SUM: rc = vk_rowgroup_sum_bf16(g->p[0], g->p[1], (int)g->n[0], (int)g->n[1], (int)g->n[2], s); break;
+                    case VK_FN_RELU_BWD: rc = vk_relu_bwd_bf16(g->p[0], g->p[1], g->p[2], g->n[0], s); break;
+                    case VK_FN_COPY: rc = vk_copy_async(g->p[0], g->p[1], g->n[0], s); break;
                     default: rc = vk::set_error("vk_run_ops: unknown generic fn %d at op %d", g->fn, i);
                 }
                 break;

@@ -277,7 +277,7 @@ class StepEngine:
         self.bwd_pro = []            # zero-fills of gradient tensors that are accumulated with atomics
         kind = cfg.image_embeddings
         bwd_stages = []
-        nemb = 1 if kind == "visualbert" else 2
+        nemb = 1 if kind in ("visualbert", "vl-bert") else 2
         self.stage_prefix = [["bert.embeddings.", "bert.v_embeddings."]] * nemb + [["bert.encoder.layer.%d." % n] for n, _ in sublayer_schedule(cfg)]
         if kind == "vilbert":
             bwd_stages.append(self._emb_text("bert.embeddings."))
@@ -290,8 +290,10 @@ class StepEngine:
             bwd_stages.append(self._emb_image_uniter("bert.embeddings."))
         elif kind == "visualbert":
             bwd_stages.append(self._emb_visualbert("bert.embeddings."))
+        elif kind == "vl-bert":
+            bwd_stages.append(self._emb_vlbert("bert.embeddings."))
         else:
-            raise NotImplementedError("image_embeddings=%r: VL-BERT's embedding path is not built yet (DESIGN.md, scope)" % kind)
+            raise NotImplementedError("image_embeddings=%r" % kind)
         self.taps["emb_t"], self.taps["emb_v"] = self.x[0], self.x[1]
         for n, typ in sublayer_schedule(cfg):
             bwd_stages.append(self._attn_sublayer(n) if typ == "attn" else self._ffn_sublayer(n))
@@ -503,6 +505,112 @@ class StepEngine:
         self.patch("input_ids", eb, "ids")
         self.patch("token_type_ids", eb, "type_ids")
         b.append((L.OP_EMBED_BWD, 0, 0, 0, eb, None, None))
+        return b
+
+    def _emb_vlbert(self, pre):
+        """VL-BERT embeddings (volta/embeddings.py:240-301): box geometry sin/cos + appearance -> dropout -> Linear(2F -> H)
+        -> ReLU = final; vision token = LN_obj(final) + (object / END) embedding + position + type 2; text token =
+        word + LN_text(final of the LAST region of the sample) + position + type; ONE LayerNorm over [text | vision].
+        Position ids follow the reference, including its expanded-view quirk (see prepare_step)."""
+        cfg, H, B = self.cfg, self.H, self.B
+        st_t, st_v = self.st
+        T, K = st_t.L, st_v.L
+        F_, dim = cfg.v_feature_size, cfg.v_coordinate_embeddings_dim
+        W = 8 * dim + F_
+        if W != 2 * F_ or W % 64 or cfg.v_hidden_size != cfg.hidden_size or cfg.visual_target_weights.get("6", 0) > 0:
+            raise NotImplementedError("VL-BERT embedding geometry outside the ctrl config (8*dim must equal v_feature_size)")
+        f, dev = self.fwd.ops, self.dev
+        i64 = dict(dtype=torch.int64, device=dev)
+        nodrop = L.dropout_cfg(None, 0, 0.0)
+        # ---- static index tensors and per-step position ids (filled in prepare_step)
+        is_last = torch.zeros(B, K, **i64)
+        is_last[:, -1] = 1
+        self.bufs["vl_is_last"] = is_last = is_last.view(-1).contiguous()
+        self.bufs["vl_twos"] = twos = torch.full((st_v.M,), 2, **i64)
+        self.bufs["vl_tpos"] = tpos = torch.zeros(st_t.M, **i64)
+        self.bufs["vl_opos"] = opos = torch.zeros(st_v.M, **i64)
+        self.bufs["vl_last_rows"] = last_rows = (torch.arange(B, device=dev, dtype=torch.int32) * K + (K - 1)).contiguous()
+        self.bufs["vl_row2b"] = row2b = (torch.arange(st_t.M, device=dev, dtype=torch.int32) // T).contiguous()
+        self.bufs["vl_cntB"] = cntB = torch.tensor([B], device=dev, dtype=torch.int32)
+        self.bufs["vl_cntMt"] = cntMt = torch.tensor([st_t.M], device=dev, dtype=torch.int32)
+        vtab = self.buf("vl_vtab", (2, H), torch.float32)
+        dvtab = self.buf("vl_dvtab", (2, H), torch.float32)
+        self._vlbert = dict(pre=pre, tpos=tpos, opos=opos, vtab=vtab, T=T, K=K)
+        # ---- forward
+        x4 = self.buf("vl_x4096", (st_v.M, W))
+        zflag = self.buf("vl_zero_flag", (st_v.M,), torch.int32)
+        dr0 = self.drop(cfg.v_attention_probs_dropout_prob)
+        g = self.generic(L.FN_VLBERT_PREP, p=(None, None, self.Pm(pre + "object_mask_visual_embedding.weight"), x4, zflag), n=(st_v.M, F_, dim, cfg.num_locs), drop=dr0)
+        self.patch("image_loc", g, "p", 0)
+        self.patch("image_feat", g, "p", 1)
+        f.append((L.OP_GENERIC, 0, 0, 0, g, None, None))
+        final = self.buf("vl_final", (st_v.M, H))
+        wds = pre + "obj_downsample.1"
+        self.gemm(f, L.NT, L.EPI_RELU, [self.prob(x4, self.W(wds + ".weight"), final, st_v.M, H, W, W, W, H, bias=self.Pm(wds + ".bias"))])
+        obj_vis = self.buf("vl_obj_vis", (st_v.M, H))
+        so = [self.buf("vl_%s" % n_, (m,), torch.float32) for n_, m in (("mean_o", st_v.M), ("rstd_o", st_v.M), ("mean_x", B), ("rstd_x", B),
+                                                                       ("mean_t", st_t.M), ("rstd_t", st_t.M), ("mean_v", st_v.M), ("rstd_v", st_v.M))]
+        f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(final, None, pre + "visual_ln_object.weight", pre + "visual_ln_object.bias", obj_vis, None, so[0], so[1], st_v.M, nodrop), None, None))
+        vz = self.buf("emb_v_z", (st_v.M, H))
+        ptab, ttab = pre + "position_embeddings.weight", pre + "token_type_embeddings.weight"
+        ev = self.k(L.EmbedArgs(_addr(is_last), _addr(twos), _addr(opos), _addr(vtab), _addr(self.Pm(ptab)), _addr(self.Pm(ttab)), _addr(obj_vis), _addr(vz),
+                                st_v.M, K, H, 2, cfg.max_position_embeddings, cfg.type_vocab_size))
+        f.append((L.OP_EMBED_FWD, 0, 0, 0, ev, None, None))
+        flast = self.buf("vl_final_last", (B, H))
+        f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_GATHER, p=(final, last_rows, cntB, flast), n=(H, B)), None, None))
+        tv = self.buf("vl_tv", (B, H))
+        f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(flast, None, pre + "visual_ln_text.weight", pre + "visual_ln_text.bias", tv, None, so[2], so[3], B, nodrop), None, None))
+        tvx = self.buf("vl_tv_exp", (st_t.M, H))
+        f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_GATHER, p=(tv, row2b, cntMt, tvx), n=(H, st_t.M)), None, None))
+        tz = self.buf("emb_t_z", (st_t.M, H))
+        et = self.k(L.EmbedArgs(None, None, _addr(tpos), _addr(self.Pm(pre + "word_embeddings.weight")), _addr(self.Pm(ptab)), _addr(self.Pm(ttab)), _addr(tvx), _addr(tz),
+                                st_t.M, T, H, cfg.vocab_size, cfg.max_position_embeddings, cfg.type_vocab_size))
+        self.patch("input_ids", et, "ids")
+        self.patch("token_type_ids", et, "type_ids")
+        f.append((L.OP_EMBED_FWD, 0, 0, 0, et, None, None))
+        yt, yv = self.buf("emb_t_y", (st_t.M, H)), self.buf("emb_v_y", (st_v.M, H))
+        dr1 = self.drop(cfg.hidden_dropout_prob)
+        seg_t = [(dr1.site, T, T + K, 0), (dr1.site, 0, 0, 0)]
+        seg_v = [(dr1.site, K, T + K, T), (dr1.site, 0, 0, 0)]
+        gn, bn = pre + "LayerNorm.weight", pre + "LayerNorm.bias"
+        f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(tz, None, gn, bn, yt, None, so[4], so[5], st_t.M, dr1, post=1, segs=seg_t), None, None))
+        f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(vz, None, gn, bn, yv, None, so[6], so[7], st_v.M, dr1, post=1, segs=seg_v), None, None))
+        self.x = [yt, yv]
+        # ---- backward
+        b = []
+        dzt, dzv = self.tmp("dz0", (st_t.M, H)), self.tmp("dz1", (st_v.M, H))
+        b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(self._dx(0, 0), tz, so[4], so[5], gn, bn, dzt, None, st_t.M, dr1, post=1, segs=seg_t), None, None))
+        b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(self._dx(1, 0), vz, so[6], so[7], gn, bn, dzv, None, st_v.M, dr1, post=1, segs=seg_v, accumulate=1), None, None))
+        self._zero_grad(self.G(ptab))
+        self._zero_grad(self.G(ttab))
+        # text tokens: word / position / type tables, and the per-sample visual vector
+        eb = self.k(L.EmbedBwdArgs(_addr(dzt), None, None, _addr(tpos), _addr(self.G(pre + "word_embeddings.weight")), _addr(self.G(ptab)), _addr(self.G(ttab)),
+                                   st_t.M, T, H, cfg.type_vocab_size, cfg.vocab_size, cfg.max_position_embeddings))
+        self.patch("input_ids", eb, "ids")
+        self.patch("token_type_ids", eb, "type_ids")
+        b.append((L.OP_EMBED_BWD, 0, 0, 0, eb, None, None))
+        dtv = self.buf("vl_dtv", (B, H))
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ROWGROUP_SUM, p=(dzt, dtv), n=(B, T, H)), None, None))
+        dflast = self.buf("vl_dfinal_last", (B, H))
+        b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dtv, flast, so[2], so[3], pre + "visual_ln_text.weight", pre + "visual_ln_text.bias", dflast, None, B, nodrop), None, None))
+        # vision tokens: (object | END) embedding, position, type 2, then LN_obj
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MEMSET, p=(dvtab,), n=(dvtab.numel() * 4, 0)), None, None))
+        evb = self.k(L.EmbedBwdArgs(_addr(dzv), _addr(is_last), _addr(twos), _addr(opos), _addr(dvtab), _addr(self.G(ptab)), _addr(self.G(ttab)),
+                                    st_v.M, K, H, cfg.type_vocab_size, 2, cfg.max_position_embeddings))
+        b.append((L.OP_EMBED_BWD, 0, 0, 0, evb, None, None))
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_COPY, p=(self.G(pre + "object_linguistic_embeddings.weight"), dvtab[0]), n=(H * 4,)), None, None))
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_COPY, p=(self.G(pre + "end_embedding.weight"), dvtab[1]), n=(H * 4,)), None, None))
+        dfinal = self.tmp("dd1", (st_v.M, H))
+        b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dzv, final, so[0], so[1], pre + "visual_ln_object.weight", pre + "visual_ln_object.bias", dfinal, None, st_v.M, nodrop), None, None))
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SCATTER_ADD, p=(dflast, last_rows, cntB, dfinal), n=(H, B)), None, None))
+        dpre = self.tmp("dctx1", (st_v.M, H))
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_RELU_BWD, p=(dfinal, final, dpre), n=(st_v.M * H,)), None, None))
+        self.gemm(b, L.TN, L.EPI_F32, [self.prob(dpre, x4, self.G(wds + ".weight"), H, W, st_v.M, H, W, W, bias_grad=self.G(wds + ".bias"))])
+        dx4 = self.buf("vl_dx4096", (st_v.M, W))
+        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dpre, self.W(wds + ".weight"), dx4, st_v.M, W, H, H, W, W)])
+        part = self.tmp("vl_mask_partial", (L.lib.vk_rows32(st_v.M) * F_,), torch.float32)
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_VLBERT_MASKGRAD, p=(dx4, zflag, part, self.G(pre + "object_mask_visual_embedding.weight")),
+                                                       n=(st_v.M, F_, W, 8 * dim), drop=dr0), None, None))
         return b
 
     # ---------------------------------------------------------------- encoder sub-layers
@@ -790,6 +898,7 @@ class StepEngine:
     # ---------------------------------------------------------------- run
     def bind_inputs(self, tensors):
         """Patch the per-step input pointers into the few ops that read user tensors."""
+        self._cur_inputs = tensors
         for name, sites in self.inputs.items():
             t = tensors[name]
             addr = t.data_ptr()
@@ -802,10 +911,36 @@ class StepEngine:
     def prepare_step(self, seed):
         if self.train:
             check(L.lib.vk_set_seed(ptr(self.seed), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), L.stream_ptr()))
+        vl = getattr(self, "_vlbert", None)
+        if vl is not None:
+            self._vlbert_positions(vl)
         v = getattr(self, "_visualbert_vec", None)
         if v is not None:
             vec, pre = v
             torch.add(self.Pm(pre + "position_embeddings_visual.weight")[0], self.Pm(pre + "token_type_embeddings_visual.weight")[1], out=vec)
+
+
+def _vlbert_positions(self, vl):
+    """Position ids of VL-BERT (volta/embeddings.py:278-292) from the step's input_ids, with device-side torch ops (no
+    host sync): text_end = number of non-pad tokens; text positions are arange(T), shifted by the number of boxes
+    wherever ANY sample of the batch has t >= its text_end (the reference applies the shift through an expanded,
+    stride-0 view, so it lands in the row shared by every sample -- kept, the oracle documents it); every box sits at
+    text_end, the last one at text_end + 1.  Also refreshes the 2-row (object | END) embedding table."""
+    ids = self._cur_inputs["input_ids"]
+    B, T, K = ids.shape[0], vl["T"], vl["K"]
+    text_end = (ids != 0).sum(1, keepdim=True)
+    ar = torch.arange(T, device=ids.device)
+    shifted = (ar[None] >= text_end).any(0)
+    vl["tpos"].view(B, T).copy_((ar + K * shifted.long())[None].expand(B, T))
+    op = vl["opos"].view(B, K)
+    op.copy_(text_end.expand(B, K))
+    op[:, -1] += 1
+    pre = vl["pre"]
+    vl["vtab"][0].copy_(self.Pm(pre + "object_linguistic_embeddings.weight")[0])
+    vl["vtab"][1].copy_(self.Pm(pre + "end_embedding.weight")[0])
+
+
+StepEngine._vlbert_positions = _vlbert_positions
 
 
 def _mk_segs(drop, segs):
