@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--regions", type=int, default=36)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--dump-ops", default=None, help="write the per-op timing table of the profiled steps to this file")
     return ap.parse_args()
 
 
@@ -205,6 +206,17 @@ def main():
                 for i, op in enumerate(plan.ops):
                     name = {L.OP_GEMM: "gemm", L.OP_LN_FWD: "ln_fwd", L.OP_LN_BWD: "ln_bwd", L.OP_ATTN_FWD: "attn_fwd", L.OP_ATTN_BWD: "attn_bwd"}.get(op[0], "other")
                     kinds[name] = kinds.get(name, 0.0) + tms["%s%d" % (tag, i)]
+            if a.dump_ops:
+                with open(a.dump_ops, "w") as fh:
+                    for plan, tag in ((eng.fwd, "f"), (eng.bwd, "b")):
+                        for i, op in enumerate(plan.ops):
+                            key = "%s%d" % (tag, i)
+                            if op[0] == L.OP_GEMM:
+                                arr, nprob = op[4], op[3]
+                                shapes = ";".join("%dx%dx%d" % (arr[j].M, arr[j].N, arr[j].K) for j in range(min(nprob, 4)))
+                                fh.write("%s gemm layout=%d epi=%d nprob=%d [%s] %.1f us %.0f TF/s\n" % (key, op[1], op[2], nprob, shapes, tms[key] * 1e3, fl[key] / (tms[key] * 1e-3) / 1e12))
+                            else:
+                                fh.write("%s kind=%d %.1f us\n" % (key, op[0], tms[key] * 1e3))
             eng.fwd.enable_timing(False)
             eng.bwd.enable_timing(False)
             ach = gemm_fl / (gemm_ms * 1e-3) / 1e12

@@ -74,7 +74,7 @@ typedef struct vk_gemm_problem {
     int32_t lda, ldb, ldc, ldr;
     int32_t n_store;       /* VK_EPI_F32: zero-fill columns up to here (>= N), else 0 */
 } vk_gemm_problem;
-#define VK_GEMM_MAX_GROUP 8
+#define VK_GEMM_MAX_GROUP 32
 /* One launch for up to VK_GEMM_MAX_GROUP independent problems of the same layout / epilogue. */
 int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, vk_stream_t s);
 
@@ -297,6 +297,11 @@ typedef struct vk_adamw_args {
 } vk_adamw_args;
 int vk_adamw_step(const vk_adamw_args* a, vk_stream_t s);
 int vk_axpy_f32(float* y, const float* x, float alpha, int64_t n, vk_stream_t s);
+/* dst[i] = sum_{s < nslabs} src[s * slab_stride + i], i < n (fp32).  Combines the partial weight gradients of a
+ * split-K wgrad: each K-chunk is an ordinary problem of the grouped TN launch writing its own slab. */
+int vk_sum_slabs_f32(float* dst, const float* src, int64_t slab_stride, int nslabs, int64_t n, vk_stream_t s);
+/* Same with a bf16 destination and a device-side row count: rows = min(*dyn_rows, n / row_len) rows of row_len. */
+int vk_sum_slabs_bf16(void* dst, const float* src, int64_t slab_stride, int nslabs, int64_t n, const int32_t* dyn_rows, int row_len, vk_stream_t s);
 int vk_memset_async(void* p, int value, int64_t bytes, vk_stream_t s);
 
 /* out[i] = a[i] * b[i] (bf16); processes rows * row_len elements where rows = min(*dyn_rows, n / row_len)
@@ -319,7 +324,7 @@ enum {
 enum {
     VK_FN_CAST = 1, VK_FN_MEMSET, VK_FN_LOC_FWD, VK_FN_LOC_BWD, VK_FN_ADD_DROPOUT, VK_FN_COLSUM, VK_FN_SELECT,
     VK_FN_GATHER, VK_FN_SCATTER_ADD, VK_FN_LOSS_FINAL, VK_FN_POOL_FWD, VK_FN_POOL_BWD, VK_FN_MASK_PREP, VK_FN_MUL,
-    VK_FN_VLBERT_PREP, VK_FN_VLBERT_MASKGRAD, VK_FN_ROWGROUP_SUM, VK_FN_RELU_BWD, VK_FN_COPY
+    VK_FN_VLBERT_PREP, VK_FN_VLBERT_MASKGRAD, VK_FN_ROWGROUP_SUM, VK_FN_RELU_BWD, VK_FN_COPY, VK_FN_SUM_SLABS, VK_FN_SUM_SLABS_BF16
 };
 typedef struct vk_generic_args {   /* positional arguments of the small entry points, see executor.cpp */
     int32_t fn;

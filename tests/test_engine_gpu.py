@@ -24,6 +24,8 @@ CONFIGS = {
     "gated": dict(BASE, image_embeddings="vilbert", tt_attn_sublayers=[0], tv_attn_sublayers=[0], vt_attn_sublayers=[0],
                   vv_attn_sublayers=[0], t_ff_sublayers=[1], v_ff_sublayers=[1]),
 }
+# larger vocabulary: exercises the split-K (slab) path of the LM-decoder dgrad
+CONFIGS["bigvocab"] = dict(CONFIGS["gated"], vocab_size=8000)
 CONFIGS["vilbert"].pop("tt_attn_sublayers_extra")
 CONFIGS["vilbert"]["tt_attn_sublayers"] = [0, 4, 6]
 CONFIGS["vilbert"]["t_ff_sublayers"] = [1, 3, 5, 7]

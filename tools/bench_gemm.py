@@ -33,18 +33,23 @@ def bench(name, layout, epi, M, N, K, iters=20):
 
 def sweep():
     import ctypes
-    L.lib.vk_gemm_set_stagger.argtypes = [ctypes.c_int]
+    L.lib.vk_gemm_set_waves256.argtypes = [ctypes.c_int]
+    L.lib.vk_gemm_set_tile.argtypes = [ctypes.c_int]
     for rnd in range(2):
-        for stg in (0, 1):
-            L.lib.vk_gemm_set_stagger(stg)
-            print("=== round", rnd, "stagger", stg, flush=True)
+        for wv in (16, 8):
+            L.lib.vk_gemm_set_waves256(wv)
+            L.lib.vk_gemm_set_tile(256)
+            print("=== round", rnd, "256x256 with", wv, "waves", flush=True)
             for Mrows, tag in ((5120, "text"), (9472, "vis")):
                 bench(tag + " qkv fwd NT", L.NT, L.EPI_BF16, Mrows, 2304, 768)
                 bench(tag + " ffn-up fwd NT gelu", L.NT, L.EPI_GELU, Mrows, 3072, 768)
                 bench(tag + " ffn-down dgrad NN", L.NN, L.EPI_BF16, Mrows, 3072, 768)
+                bench(tag + " ffn wgrad TN", L.TN, L.EPI_F32, 3072, 768, Mrows)
             bench("square 4096", L.NT, L.EPI_BF16, 4096, 4096, 4096)
+            bench("square 4096 TN", L.TN, L.EPI_F32, 4096, 4096, 4096)
             bench("square 8192", L.NT, L.EPI_BF16, 8192, 8192, 8192, iters=5)
-    L.lib.vk_gemm_set_stagger(1)
+    L.lib.vk_gemm_set_waves256(16)
+    L.lib.vk_gemm_set_tile(0)
 
 
 if __name__ == "__main__":

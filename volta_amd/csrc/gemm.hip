@@ -26,8 +26,8 @@
 namespace vk {
 
 constexpr int BK = 64;
-template <int WM, int WN> struct Geo {
-    static constexpr int THREADS = 64 * WM * WN, BM = 64 * WM, BN = 64 * WN;
+template <int WM, int WN, int TM = 1> struct Geo {      // TM: 64-row blocks per wave (wave tile = 64*TM x 64)
+    static constexpr int THREADS = 64 * WM * WN, BM = 64 * TM * WM, BN = 64 * WN;
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
 };
 
@@ -105,9 +105,10 @@ __device__ __forceinline__ bf16x8 frag_cols(uint32_t tile, int c0, int ks, int l
     return r;
 }
 
-template <bool AT, bool BT, int EPI, int WM, int WN, bool REGSTAGE>
+template <bool AT, bool BT, int EPI, int WM, int WN, bool REGSTAGE, int TM = 1>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const KGroup g) {
-    using G = Geo<WM, WN>;
+    using G = Geo<WM, WN, TM>;
+    constexpr int TI = 4 * TM;            // 16-row MFMA tiles per wave along M
     constexpr int THREADS = G::THREADS, BM = G::BM, BN = G::BN;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(VK_LDS char*)smem;
@@ -144,14 +145,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const KGroup g) {
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(P.A, a_rows > 0 ? (uint32_t)(((uint32_t)(a_rows - 1) * P.lda + a_cols) * 2u) : 0u);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(P.B, b_rows > 0 ? (uint32_t)(((uint32_t)(b_rows - 1) * P.ldb + b_cols) * 2u) : 0u);
 
-    f32x4 acc[4][4];
+    f32x4 acc[TI][4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 accb[4];
+    f32x4 accb[TI];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TI; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool do_bias_grad = AT && BT && (P.bias_grad != nullptr) && (tn == 0) && (wn == 0);
     bf16x8 ones;
 #pragma unroll
@@ -161,20 +162,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const KGroup g) {
     auto compute_ks = [&](int cur, int ks) {
         const uint32_t ta = lds0 + cur * G::STAGE, tb = ta + G::A_BYTES;
         {
-            bf16x8 a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                a[i] = AT ? frag_cols<BM * 2>(ta, wm * 64 + i * 16, ks, lane) : frag_rows(ta, wm * 64 + i * 16, ks, lane);
-                b[i] = BT ? frag_cols<BN * 2>(tb, wn * 64 + i * 16, ks, lane) : frag_rows(tb, wn * 64 + i * 16, ks, lane);
-            }
+            bf16x8 a[TI], b[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
+                b[i] = BT ? frag_cols<BN * 2>(tb, wn * 64 + i * 16, ks, lane) : frag_rows(tb, wn * 64 + i * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                a[i] = AT ? frag_cols<BM * 2>(ta, wm * 64 * TM + i * 16, ks, lane) : frag_rows(ta, wm * 64 * TM + i * 16, ks, lane);
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
             if (do_bias_grad) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i], accb[i], 0, 0, 0);
+                for (int i = 0; i < TI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i], accb[i], 0, 0, 0);
             }
         }
     };
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const KGroup g) {
         // Waves 4..7 and 12..15 of a 16-wave workgroup share their SIMDs with waves 0..3 / 8..11: they issue the DMA of
         // the next tile after their first 16 MFMAs instead of before them, so that on every SIMD two waves feed the
         // matrix pipe while the other two pay the LDS-DMA issue cost (60-185 cycles per piece).
-        const bool late = g.stagger && (WM * WN > 4) && ((__builtin_amdgcn_readfirstlane(wave) >> 2) & 1);
+        const bool late = g.stagger && (WM * WN > 4) && ((__builtin_amdgcn_readfirstlane(wave) >> 2) & 1);   // SIMD partners: w, w+4, ...
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();          // tile kt landed for every wave; everyone is done reading tile kt-1
@@ -246,8 +248,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const KGroup g) {
     constexpr bool F32OUT = (EPI == VK_EPI_F32 || EPI == VK_EPI_F32_ACC);
     const int nlim = (F32OUT && P.n_store > N) ? P.n_store : N;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + lr;
+    for (int i = 0; i < TI; ++i) {
+        const int m = m0 + wm * 64 * TM + i * 16 + lr;
         if (m >= Mout) continue;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -308,20 +310,20 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const KGroup g) {
     }
     if (do_bias_grad && gq == 0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + lr;
+        for (int i = 0; i < TI; ++i) {
+            const int m = m0 + wm * 64 * TM + i * 16 + lr;
             if (m < Mout) P.bias_grad[m] = (EPI == VK_EPI_F32_ACC ? P.bias_grad[m] : 0.f) + accb[i][0];
         }
     }
 }
 
-template <bool AT, bool BT, int WM, int WN, bool REGSTAGE>
+template <bool AT, bool BT, int WM, int WN, bool REGSTAGE, int TM = 1>
 static int launch_cfg(int epi, const KGroup& g, int total, hipStream_t s) {
-    using G = Geo<WM, WN>;
+    using G = Geo<WM, WN, TM>;
     constexpr int LDS = 2 * G::STAGE;
 #define VK_CASE(E)                                                                                        \
     case E: {                                                                                             \
-        auto k = gemm_kernel<AT, BT, E, WM, WN, REGSTAGE>;                                                \
+        auto k = gemm_kernel<AT, BT, E, WM, WN, REGSTAGE, TM>;                                                \
         static bool once = false;                                                                         \
         if (!once) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; } \
         hipLaunchKernelGGL(k, dim3(total), dim3(G::THREADS), LDS, s, g);                                  \
@@ -337,6 +339,7 @@ static int launch_cfg(int epi, const KGroup& g, int total, hipStream_t s) {
 
 static int g_tile_override = 0;       // tuning hook: 0 = heuristic, 128 / 192 / 256 = force 128x128 / 256x128 / 256x256
 static int g_stagger = 1;
+static int g_waves256 = 16;          // waves of the 256x256 geometry: 16 (64x64 each) or 8 (128x64 each)
 static int g_regstage_override = -1;  // -1 = heuristic, 0 / 1 = force LDS-DMA / register staging (128^2 only)
 
 static int total_tiles(const vk_gemm_problem* probs, int nprob, int epilogue, int bm, int bn) {
@@ -392,7 +395,11 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
     }
     if (total == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (edge == 256) {
+    if (edge == 256 && g_waves256 == 8) {      // 256x256 with 8 waves of 128x64 (2 x 4)
+        if (layout == VK_NT) return launch_cfg<false, false, 2, 4, false, 2>(epilogue, g, total, s);
+        if (layout == VK_NN) return launch_cfg<false, true, 2, 4, false, 2>(epilogue, g, total, s);
+        if (layout == VK_TN) return launch_cfg<true, true, 2, 4, false, 2>(epilogue, g, total, s);
+    } else if (edge == 256) {
         if (layout == VK_NT) return launch_cfg<false, false, 4, 4, false>(epilogue, g, total, s);
         if (layout == VK_NN) return launch_cfg<false, true, 4, 4, false>(epilogue, g, total, s);
         if (layout == VK_TN) return launch_cfg<true, true, 4, 4, false>(epilogue, g, total, s);
@@ -413,3 +420,4 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
 extern "C" void vk_gemm_set_tile(int edge) { vk::g_tile_override = edge; }
 extern "C" void vk_gemm_set_regstage(int v) { vk::g_regstage_override = v; }
 extern "C" void vk_gemm_set_stagger(int v) { vk::g_stagger = v; }
+extern "C" void vk_gemm_set_waves256(int v) { vk::g_waves256 = v; }

@@ -74,9 +74,61 @@ __global__ __launch_bounds__(256) void axpy_kernel(float* y, const float* x, flo
     }
 }
 
+__global__ __launch_bounds__(256) void sum_slabs_kernel(float* dst, const float* src, size_t stride, int nslabs, size_t n) {
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 a = *(const f32x4*)(src + i * 4);
+        for (int s = 1; s < nslabs; ++s) {
+            const f32x4 b = *(const f32x4*)(src + (size_t)s * stride + i * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] += b[r];
+        }
+        *(f32x4*)(dst + i * 4) = a;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        const size_t i = n4 * 4 + threadIdx.x;
+        float a = 0.f;
+        for (int s = 0; s < nslabs; ++s) a += src[(size_t)s * stride + i];
+        dst[i] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void sum_slabs_bf16_kernel(uint16_t* dst, const float* src, size_t stride, int nslabs, size_t n, const int32_t* dyn_rows, int row_len) {
+    if (dyn_rows) { const size_t lim = (size_t)(*dyn_rows) * row_len; if (lim < n) n = lim; }
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 a = *(const f32x4*)(src + i * 4);
+        for (int s = 1; s < nslabs; ++s) {
+            const f32x4 b = *(const f32x4*)(src + (size_t)s * stride + i * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a[r] += b[r];
+        }
+        *(u32x2*)(dst + i * 4) = u32x2{pack2bf(a[0], a[1]), pack2bf(a[2], a[3])};
+    }
+}
+
 }  // namespace vk
 
 using namespace vk;
+
+extern "C" int vk_sum_slabs_bf16(void* dst, const float* src, int64_t slab_stride, int nslabs, int64_t n, const int32_t* dyn_rows, int row_len, vk_stream_t s) {
+    if (n <= 0 || nslabs <= 0) return 0;
+    if ((slab_stride & 3) || (n & 3) || (row_len & 3)) return set_error("vk_sum_slabs_bf16: lengths must be multiples of 4");
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sum_slabs_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, (uint16_t*)dst, src, (size_t)slab_stride, nslabs, (size_t)n, dyn_rows, row_len);
+    return check_launch("vk_sum_slabs_bf16");
+}
+
+extern "C" int vk_sum_slabs_f32(float* dst, const float* src, int64_t slab_stride, int nslabs, int64_t n, vk_stream_t s) {
+    if (n <= 0 || nslabs <= 0) return 0;
+    if ((slab_stride & 3) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 15)) return set_error("vk_sum_slabs_f32: 16-byte alignment required");
+    int64_t blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sum_slabs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, dst, src, (size_t)slab_stride, nslabs, (size_t)n);
+    return check_launch("vk_sum_slabs_f32");
+}
 
 extern "C" int vk_grad_norm_workspace_floats(void) { return NORM_BLOCKS; }
 

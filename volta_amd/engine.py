@@ -751,19 +751,57 @@ class StepEngine:
         return b
 
     def _wgrad(self, b, ms, shared, specs):
-        """dW[Mo, No] = dY^T X (+ bias grad) for every spec and modality in one grouped TN launch; weights shared by
-        both modalities: the first modality's launch overwrites, the second one's accumulates."""
-        per_m = {}
-        for m in ms:
-            per_m[m] = []
-            for spec in specs:
+        """dW[Mo, No] = dY^T X (+ bias grad) for every spec and modality in ONE grouped TN launch.  The outputs are
+        small (<= 3072 x 768) and the contraction (B*L rows) long, so every problem is split along K into chunks of
+        ~5120 rows: each chunk is an ordinary problem writing its own fp32 slab (weights | bias), and one reduction
+        pass sums the slabs into the gradient arena (plain stores: float atomics would cost 4x the slab traffic).
+        This turns 36-144 long tiles into >= 256 balanced ones that take the 256x256 geometry.  Weights shared by
+        both modalities simply sum the slabs of both."""
+        jobs = []            # (dst weight grad, dst bias grad, Mo, No, [(dY, X, rows, lda, ldb), ...])
+        for spec in specs:
+            per_w = {}
+            for m in ms:
                 dY, X, gW, gB, Mo, No, lda, ldb = spec(m)
-                per_m[m].append(self.prob(dY, X, gW, Mo, No, self.st[m].M, lda, ldb, No, bias_grad=gB))
-        if shared and len(ms) == 2:
-            self.gemm(b, L.TN, L.EPI_F32, per_m[ms[0]])
-            self.gemm(b, L.TN, L.EPI_F32_ACC, per_m[ms[1]])
-        else:
-            self.gemm(b, L.TN, L.EPI_F32, [p for m in ms for p in per_m[m]])
+                key = gW.data_ptr()
+                per_w.setdefault(key, (gW, gB, Mo, No, []))[4].append((dY, X, self.st[m].M, lda, ldb))
+            jobs += list(per_w.values())
+        probs, reduces = [], []
+        for gW, gB, Mo, No, srcs in jobs:
+            chunks = []
+            for dY, X, rows, lda, ldb in srcs:
+                ns = max(1, int(round(rows / 5120.0)))
+                step = -(-rows // ns)
+                step = -(-step // 64) * 64
+                r0 = 0
+                while r0 < rows:
+                    chunks.append((dY[r0:], X[r0:], min(step, rows - r0), lda, ldb))
+                    r0 += step
+            if len(chunks) == 1:
+                dY, X, rows, lda, ldb = chunks[0]
+                probs.append(self.prob(dY, X, gW, Mo, No, rows, lda, ldb, No, bias_grad=gB))
+                continue
+            stride = _round_up(Mo * No + Mo, 4)
+            slab = self._slab(len(chunks) * stride)
+            for i, (dY, X, rows, lda, ldb) in enumerate(chunks):
+                base = slab[i * stride:]
+                probs.append(self.prob(dY, X, base, Mo, No, rows, lda, ldb, No, bias_grad=base[Mo * No:]))
+            reduces.append((gW, slab, stride, len(chunks), Mo * No))
+            reduces.append((gB, slab[Mo * No:], stride, len(chunks), Mo))
+        assert len(probs) <= 32, "too many wgrad problems in one group"
+        self.gemm(b, L.TN, L.EPI_F32, probs)
+        for dst, src, stride, ns, n in reduces:
+            b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SUM_SLABS, p=(dst, src), n=(stride, ns, n)), None, None))
+        self._slab_cursor = 0
+
+    def _slab(self, n):
+        """fp32 workspace for split-K partials; one arena reused by every sub-layer (launches are stream-ordered)."""
+        cap = 40 * 3072 * 768
+        ws = self.tmp("wgrad_slabs", (cap,), torch.float32)
+        cur = getattr(self, "_slab_cursor", 0)
+        cur = _round_up(cur, 4)
+        assert cur + n <= cap, "wgrad slab workspace too small"
+        self._slab_cursor = cur + n
+        return ws[cur:cur + n]
 
     # ---------------------------------------------------------------- heads + losses
     def _heads(self):
@@ -853,7 +891,23 @@ class StepEngine:
         dlog_t = self.buf("lm_dlogits", (st_t.M, Vp))
         b.append((L.OP_XENT_BWD, Vp, 0, 0, xa, dlog_t, self.gout[0:1]))
         dhn_t = self.tmp("head_d1", (max(st_t.M, Mr), H))
-        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dlog_t, self.W(wword), dhn_t, st_t.M, H, V, Vp, H, H, dyn=n_t)])
+        # d(hidden) = dlogits[n_t, V] . E[V, H]: few rows, very long contraction -> split K over the vocabulary into
+        # chunks written as fp32 slabs by one grouped launch, then summed (and rounded to bf16) in one pass
+        nsplit = max(1, min(16, V // 1920))
+        if nsplit == 1:
+            self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dlog_t, self.W(wword), dhn_t, st_t.M, H, V, Vp, H, H, dyn=n_t)])
+        else:
+            kc = _round_up(-(-V // nsplit), 64)
+            stride = st_t.M * H
+            slabs = self.buf("lm_dgrad_slabs", (nsplit * stride,), torch.float32)
+            probs, k0, wv = [], 0, self.W(wword)
+            while k0 < V:
+                kk = min(kc, V - k0)
+                i = len(probs)
+                probs.append(self.prob(dlog_t[:, k0:], wv[k0:], slabs[i * stride:], st_t.M, H, kk, Vp, H, H, dyn=n_t))
+                k0 += kc
+            self.gemm(b, L.NN, L.EPI_F32, probs)
+            b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SUM_SLABS_BF16, p=(dhn_t, slabs, n_t), n=(stride, len(probs), stride, H)), None, None))
         self.gemm(b, L.TN, L.EPI_F32, [self.prob(dlog_t, hn_t, self.G(wword), V, H, st_t.M, Vp, H, H, bias_grad=self.G(c + "bias"), dyn=n_t)])
         dht = self.tmp("head_d2", (max(st_t.M, Mr), H))
         b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dhn_t, ht, lm_mean, lm_rstd, c + "transform.LayerNorm.weight", c + "transform.LayerNorm.bias", dht, None, st_t.M, nodrop, dyn=n_t), None, None))
