@@ -225,6 +225,13 @@ def main():
                 "algorithmic_gflop_per_step": gemm_fl / 1e9, "ms_per_step": gemm_ms, "avg_launch_us": gemm_ms * 1e3 / len(fl),
                 "achieved": ach, "frac": ach / PEAK_BF16_TFLOPS, "timing": "HIP events on the launch stream, %d profiled steps" % nprof}
             out["kernel_ms_per_step"] = {k: round(v, 3) for k, v in sorted(kinds.items(), key=lambda kv: -kv[1])}
+            # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the figure is the
+            # one of the committed rocprofv3 --pmc passes over this same command (profiles/r01_pmc_hbm_traffic.md)
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
+            if os.path.exists(pmc) and a.config == "ctrl_vilbert_base" and a.batch == 256:
+                pm = json.load(open(pmc))
+                out["roofline"]["traffic"] = pm["hbm_bytes_per_launch"]
+                out["roofline"]["traffic_note"] = "bytes per GEMM launch (avg of %d launches/step), FETCH_SIZE x2 + WRITE_SIZE from profiles/r01_pmc_summary.json" % pm["launches_per_step"]
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.config, a.seq_len, a.regions)

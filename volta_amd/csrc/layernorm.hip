@@ -12,7 +12,7 @@ namespace vk {
 
 constexpr float LN_EPS = 1e-12f;
 constexpr int LN_THREADS = 256;
-constexpr int LN_BWD_ROWS = 8;      // rows per workgroup in the backward (2 per wave): >= 640 workgroups at B = 256
+constexpr int LN_BWD_ROWS = 16;     // rows per workgroup in the backward (4 per wave, all requested up front)
 
 // Philox row of `row` under the two-segment mapping of vk_ln_args.seg (see include/volta_hip.h)
 __device__ __forceinline__ uint32_t drop_row(const vk_drop_rows (&seg)[2], int split, int row, uint32_t& site) {
@@ -125,14 +125,32 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(vk_ln_bwd_args a) {
         for (int r = 0; r < 4; ++r) pg[j][r] = pb[j][r] = 0.f;
 
     const int Mrows = a.dyn ? min(*a.dyn, a.M) : a.M;
-    for (int it = 0; it < LN_BWD_ROWS / 4; ++it) {
+    // Each wave owns LN_BWD_ROWS / 4 rows; the bf16 inputs of ALL of them are requested up front (raw 8-byte
+    // loads, 2 VGPRs per 4 elements) so that several rows' worth of HBM latency overlap instead of being paid
+    // one row after the other.
+    constexpr int RPW = LN_BWD_ROWS / 4;
+    u32x2 rdy[RPW][NCH], rz[RPW][NCH];
+#pragma unroll
+    for (int it = 0; it < RPW; ++it) {
+        const int row = blockIdx.x * LN_BWD_ROWS + it * 4 + wave;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = j * 256 + lane * 4;
+            rdy[it][j] = u32x2{0u, 0u};
+            rz[it][j] = u32x2{0u, 0u};
+            if (row < Mrows && c < H) {
+                rdy[it][j] = *(const u32x2*)((const uint16_t*)a.dy + (size_t)row * H + c);
+                rz[it][j] = *(const u32x2*)((const uint16_t*)a.z + (size_t)row * H + c);
+            }
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < RPW; ++it) {
         const int row = blockIdx.x * LN_BWD_ROWS + it * 4 + wave;
         if (row >= Mrows) break;
         uint32_t dsite;
         const uint32_t drow = drop_row(a.seg, a.split_row, row, dsite);
         DropCfg dcfg{a.drop.seed, dsite, a.drop.threshold, a.drop.scale};
-        const uint16_t* dy = (const uint16_t*)a.dy + (size_t)row * H;
-        const uint16_t* z = (const uint16_t*)a.z + (size_t)row * H;
         const float mean = a.mean[row], rstd = a.rstd[row];
         float xh[NCH][4], gh[NCH][4];
         u32x4 words[NCH];
@@ -143,9 +161,9 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(vk_ln_bwd_args a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) xh[j][r] = gh[j][r] = 0.f;
             if (c < H) {
-                float dv[4], zv[4];
-                load4(dy + c, dv);
-                load4(z + c, zv);
+                const u32x2 d2 = rdy[it][j], z2 = rz[it][j];
+                const float dv[4] = {bf2f(d2[0] & 0xFFFF), bf2f(d2[0] >> 16), bf2f(d2[1] & 0xFFFF), bf2f(d2[1] >> 16)};
+                const float zv[4] = {bf2f(z2[0] & 0xFFFF), bf2f(z2[0] >> 16), bf2f(z2[1] & 0xFFFF), bf2f(z2[1] >> 16)};
                 if (drop_on) words[j] = drop_words(dcfg, seed, drow, (uint32_t)(c >> 2));
                 const f32x4 g = *(const f32x4*)(a.gamma + c);
 #pragma unroll
