@@ -55,8 +55,14 @@ def attn(gate, T=20, R=37, B=256, nh=12, H=768):
 
 
 if __name__ == "__main__":
+    import ctypes
     ln(5120)
     ln(9472)
-    attn([[1, 0], [0, 0]])
-    attn([[1, 0], [0, 1]])
-    attn([[0, 1], [1, 0]])
+    L.lib.vk_attn_set_bwd_occupancy.argtypes = [ctypes.c_int]
+    L.lib.vk_attn_set_bwd_waves.argtypes = [ctypes.c_int]
+    for wv in (8, 4, 5, 6, 3):
+        L.lib.vk_attn_set_bwd_waves(wv)
+        print("--- attn bwd waves per workgroup", wv)
+        attn([[1, 0], [0, 0]])
+        attn([[1, 0], [0, 1]])
+        attn([[0, 1], [1, 0]])

@@ -190,8 +190,10 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnK a) {
 }
 
 // ------------------------------------------------------------------------------------------------ backward
-template <int TP, int RP>
-__global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnK a) {
+// OCC = waves per SIMD the register allocation is tuned for: 2 -> <= 256 VGPRs (one 8-wave workgroup per CU), 3 -> <= 168
+// VGPRs so that two 5-wave workgroups share a CU and one's staging phase overlaps the other's MFMA phase.
+template <int TP, int RP, int OCC>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void attn_bwd_kernel(const AttnK a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(VK_LDS char*)smem;
     constexpr int PADS[2] = {TP, RP};
@@ -276,6 +278,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnK a) {
                         f32x4 pd[2], ds[2];                                                                \
                         _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                 \
                             const int qt = pp * 2 + hh;                                                    \
+                            pd[hh] = f32x4{0.f, 0.f, 0.f, 0.f}; ds[hh] = f32x4{0.f, 0.f, 0.f, 0.f};        \
+                            if (qt * 16 >= Lq) continue;         /* tile of padding rows only */          \
                             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};                     \
                             s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(qimg[MQ], qt * 16, 0, lane), kf0, s, 0, 0, 0); \
                             s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(qimg[MQ], qt * 16, 1, lane), kf1, s, 0, 0, 0); \
@@ -341,6 +345,8 @@ __global__ __launch_bounds__(512) void attn_bwd_kernel(const AttnK a) {
                         f32x4 ds[2];                                                                       \
                         _Pragma("unroll") for (int hh = 0; hh < 2; ++hh) {                                 \
                             const int kt = pp * 2 + hh;                                                    \
+                            ds[hh] = f32x4{0.f, 0.f, 0.f, 0.f};                                            \
+                            if (kt * 16 >= Lk) continue;         /* tile of padding keys only */          \
                             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};                     \
                             s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg[MK], kt * 16, 0, lane), qf0, s, 0, 0, 0); \
                             s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg[MK], kt * 16, 1, lane), qf1, s, 0, 0, 0); \
@@ -410,14 +416,25 @@ static int launch_fwd(const AttnK& k, int nq_tiles, hipStream_t s) {
     hipLaunchKernelGGL((attn_fwd_kernel<TP, RP>), dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
     return check_launch("vk_gated_attn_fwd");
 }
+static int g_attn_bwd_waves = 4;    // waves per workgroup (tasks are looped): 4 lets two workgroups share a CU (measured -15 %)
+static int g_attn_bwd_occ = 2;      // tuning hook (tools/bench_small.py); 3 measured slower (spills), kept for reference
+
 template <int TP, int RP>
 static int launch_bwd(const AttnK& k, int ntasks, hipStream_t s) {
     const int lds = 4 * (TP + RP) * 128 + 2 * (TP + RP) * 4;
-    auto kern = attn_bwd_kernel<TP, RP>;
-    static bool once = false;
-    if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
-    int waves = ntasks < 1 ? 1 : (ntasks > 8 ? 8 : ntasks);
-    hipLaunchKernelGGL(kern, dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
+    if (g_attn_bwd_occ == 3) {
+        auto kern = attn_bwd_kernel<TP, RP, 3>;
+        static bool once = false;
+        if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
+        int waves = ntasks < 1 ? 1 : (ntasks > 5 ? 5 : ntasks);
+        hipLaunchKernelGGL(kern, dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
+    } else {
+        auto kern = attn_bwd_kernel<TP, RP, 2>;
+        static bool once = false;
+        if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
+        int waves = ntasks < 1 ? 1 : (ntasks > g_attn_bwd_waves ? g_attn_bwd_waves : ntasks);
+        hipLaunchKernelGGL(kern, dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
+    }
     return check_launch("vk_gated_attn_bwd");
 }
 
@@ -455,3 +472,5 @@ extern "C" int vk_gated_attn_bwd(const vk_attn_args* a, const vk_attn_bwd_args* 
     if (!bigT && bigR) return launch_bwd<32, 128>(k, nt, s);
     return launch_bwd<64, 128>(k, nt, s);
 }
+extern "C" void vk_attn_set_bwd_occupancy(int v) { vk::g_attn_bwd_occ = v; }
+extern "C" void vk_attn_set_bwd_waves(int v) { vk::g_attn_bwd_waves = v; }
