@@ -32,29 +32,91 @@ def bench(name, layout, epi, M, N, K, iters=20):
 
 
 def sweep():
+    """A/B of the tile geometries in one process: 128 x 128, 256 x 256 8-phase, legacy 16-wave 256 x 256."""
     import ctypes
-    L.lib.vk_gemm_set_waves256.argtypes = [ctypes.c_int]
     L.lib.vk_gemm_set_tile.argtypes = [ctypes.c_int]
-    for rnd in range(2):
-        for wv in (16, 8):
-            L.lib.vk_gemm_set_waves256(wv)
-            L.lib.vk_gemm_set_tile(256)
-            print("=== round", rnd, "256x256 with", wv, "waves", flush=True)
-            for Mrows, tag in ((5120, "text"), (9472, "vis")):
-                bench(tag + " qkv fwd NT", L.NT, L.EPI_BF16, Mrows, 2304, 768)
-                bench(tag + " ffn-up fwd NT gelu", L.NT, L.EPI_GELU, Mrows, 3072, 768)
-                bench(tag + " ffn-down dgrad NN", L.NN, L.EPI_BF16, Mrows, 3072, 768)
-                bench(tag + " ffn wgrad TN", L.TN, L.EPI_F32, 3072, 768, Mrows)
-            bench("square 4096", L.NT, L.EPI_BF16, 4096, 4096, 4096)
-            bench("square 4096 TN", L.TN, L.EPI_F32, 4096, 4096, 4096)
-            bench("square 8192", L.NT, L.EPI_BF16, 8192, 8192, 8192, iters=5)
-    L.lib.vk_gemm_set_waves256(16)
+    for edge in (256, 257, 128, 256):
+        L.lib.vk_gemm_set_tile(edge)
+        print("=== tile", edge, flush=True)
+        for Mrows, tag in ((5120, "text"), (9472, "vis")):
+            bench(tag + " qkv fwd NT", L.NT, L.EPI_BF16, Mrows, 2304, 768)
+            bench(tag + " out fwd NT", L.NT, L.EPI_BF16, Mrows, 768, 768)
+            bench(tag + " ffn-up fwd NT gelu", L.NT, L.EPI_GELU, Mrows, 3072, 768)
+            bench(tag + " ffn-down fwd NT", L.NT, L.EPI_BF16, Mrows, 768, 3072)
+            bench(tag + " ffn-up dgrad NN", L.NN, L.EPI_BF16, Mrows, 768, 3072)
+            bench(tag + " ffn-down dgrad NN", L.NN, L.EPI_BF16, Mrows, 3072, 768)
+            bench(tag + " ffn wgrad TN", L.TN, L.EPI_F32, 3072, 768, Mrows)
+        bench("square 4096", L.NT, L.EPI_BF16, 4096, 4096, 4096)
+        bench("square 4096 NN", L.NN, L.EPI_BF16, 4096, 4096, 4096)
+        bench("square 4096 TN", L.TN, L.EPI_F32, 4096, 4096, 4096)
+        bench("square 8192", L.NT, L.EPI_BF16, 8192, 8192, 8192, iters=5)
     L.lib.vk_gemm_set_tile(0)
+
+
+def ablate():
+    """Ablation of the 256 x 256 kernel's main loop: what does a K-tile cost without its DMA / MFMA / LDS reads?"""
+    import ctypes
+    L.lib.vk_gemm_set_tile.argtypes = [ctypes.c_int]
+    L.lib.vk_gemm_set_debug.argtypes = [ctypes.c_int]
+    L.lib.vk_gemm_set_tile(256)
+    for dbg, tag in ((0, "full"), (1, "no DMA in loop"), (2, "no MFMA"), (4, "no LDS reads"), (3, "no DMA, no MFMA"), (5, "no DMA, no LDS reads"), (6, "no MFMA, no LDS reads"), (7, "barriers only"), (0, "full")):
+        L.lib.vk_gemm_set_debug(dbg)
+        print("=== ablation:", tag, flush=True)
+        bench("text qkv fwd NT", L.NT, L.EPI_BF16, 5120, 2304, 768)
+        bench("text ffn-down dgrad NN", L.NN, L.EPI_BF16, 5120, 3072, 768)
+        bench("deep K one wave of tiles", L.NT, L.EPI_BF16, 4096, 4096, 8192)
+        bench("square 8192", L.NT, L.EPI_BF16, 8192, 8192, 8192, iters=5)
+    L.lib.vk_gemm_set_debug(0)
+    L.lib.vk_gemm_set_tile(0)
+
+
+def blas(name, layout, M, N, K, iters=20):
+    """Vendor BLAS (torch.matmul -> hipBLASLt) on the same shape: a known-good yardstick for the headroom, never part of the product."""
+    g = torch.Generator(device="cuda").manual_seed(0)
+    rnd = lambda *s: (torch.randn(*s, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
+    if layout == L.NT:
+        A, B = rnd(M, K), rnd(N, K).t()
+    elif layout == L.NN:
+        A, B = rnd(M, K), rnd(K, N)
+    else:
+        A, B = rnd(K, M).t(), rnd(K, N)
+    C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    for _ in range(3):
+        torch.matmul(A, B, out=C)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        torch.matmul(A, B, out=C)
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    print("%-28s M=%5d N=%5d K=%5d  %8.1f us  %7.1f TF/s  (vendor BLAS)" % (name, M, N, K, ms * 1e3, 2.0 * M * N * K / ms / 1e9), flush=True)
+
+
+def vendor():
+    for Mrows, tag in ((5120, "text"), (9472, "vis")):
+        blas(tag + " qkv fwd NT", L.NT, Mrows, 2304, 768)
+        blas(tag + " out fwd NT", L.NT, Mrows, 768, 768)
+        blas(tag + " ffn-up fwd NT", L.NT, Mrows, 3072, 768)
+        blas(tag + " ffn-down fwd NT", L.NT, Mrows, 768, 3072)
+        blas(tag + " ffn-up dgrad NN", L.NN, Mrows, 768, 3072)
+        blas(tag + " ffn-down dgrad NN", L.NN, Mrows, 3072, 768)
+        blas(tag + " ffn wgrad TN", L.TN, 3072, 768, Mrows)
+        blas(tag + " out wgrad TN", L.TN, 768, 768, Mrows)
+    blas("square 4096", L.NT, 4096, 4096, 4096)
+    blas("square 8192", L.NT, 8192, 8192, 8192, iters=5)
 
 
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "sweep":
         sweep()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "ablate":
+        ablate()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "vendor":
+        vendor()
         sys.exit(0)
     for Mrows, tag in ((5120, "text"), (9472, "vis")):
         bench(tag + " qkv fwd NT", L.NT, L.EPI_BF16, Mrows, 2304, 768)

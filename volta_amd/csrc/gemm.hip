@@ -1,15 +1,14 @@
-// Grouped bf16 GEMM for gfx950 (v_mfma_f32_16x16x32_bf16, fp32 accumulate).  One kernel skeleton, three
-// operand layouts, two tile geometries, fused epilogues:
+// Grouped bf16 GEMM for gfx950 (v_mfma_f32_16x16x32_bf16, fp32 accumulate): dispatcher + the 128 x 128 tile.
+// Three operand layouts, fused epilogues (gemm_common.h):
 //   NT  both operands K-contiguous            -> fragments by ds_read_b128 from an XOR-swizzled image
 //   NN  B stored [K][N]                       -> B fragments by ds_read_b64_tr_b16 (hardware transpose)
 //   TN  A stored [K][M], B stored [K][N]      -> both by ds_read_b64_tr_b16
-// Geometry: WM x WN waves, each owning a 64 x 64 output sub-tile (4 x 4 MFMA tiles), BK = 64:
-//   2 x 2 = 128 x 128 tile,  256 threads, 32 KiB LDS per stage, 2 workgroups / CU
-//   4 x 2 = 256 x 128 tile,  512 threads, 48 KiB LDS per stage, 1 workgroup / CU (2 waves / SIMD)
-//   4 x 4 = 256 x 256 tile, 1024 threads, 64 KiB LDS per stage, 1 workgroup / CU (4 waves / SIMD)
-// Measured on MI355X (profiles/r01_gemm_*.txt): a 128^2 tile needs 32 KiB of LDS fill per 512 MFMA cycles,
-// i.e. the whole LDS write rate of a CU, so it saturates at ~45 % of the MFMA peak whatever the pipeline
-// depth; the 256^2 tile halves the fill per FLOP and is used whenever it still yields enough workgroups.
+// Two geometries:
+//   128 x 128, 4 waves (64 x 64 each), 32 KiB LDS per stage, several workgroups per CU (this file).  Measured on
+//       MI355X (profiles/r01_gemm_*.txt) it needs 32 KiB of LDS fill per 512 MFMA cycles, i.e. the whole LDS write
+//       rate of a CU, and saturates at ~45 % of the MFMA peak; it serves the problems too small to fill the chip
+//       with 256^2 tiles.
+//   256 x 256, 8 waves, 128 KiB LDS, 8-phase LDS-DMA pipeline (gemm256.hip) for everything else.
 // Staging: bounds-checked LDS-DMA (buffer_load ... lds, 16 B / lane, out-of-range rows read as 0, which is
 // what zero-pads ragged M / N / K) into a double buffer, the swizzle lives on the per-lane GLOBAL source
 // address and on the read address (cdna guide rule 21).  The 128^2 NN / TN kernels stage through registers
@@ -19,32 +18,14 @@
 //
 // Replaces every nn.Linear forward/backward of volta/encoders.py and volta/embeddings.py
 // (site list in include/volta_hip.h).
-#include "common.h"
-#include "../../include/volta_hip.h"
-#include "util.h"
+#include "gemm_common.h"
 
 namespace vk {
 
-constexpr int BK = 64;
 template <int WM, int WN, int TM = 1> struct Geo {      // TM: 64-row blocks per wave (wave tile = 64*TM x 64)
     static constexpr int THREADS = 64 * WM * WN, BM = 64 * TM * WM, BN = 64 * WN;
     static constexpr int A_BYTES = BM * BK * 2, B_BYTES = BN * BK * 2, STAGE = A_BYTES + B_BYTES;
 };
-
-struct KProb {
-    const char* A; const char* B; char* C; char* C2; const float* bias; const char* R; float* bias_grad;
-    const int32_t* dyn;
-    int32_t M, N, K, lda, ldb, ldc, ldr, n_store;
-    int32_t tiles_n, tile_start;
-};
-struct KGroup {
-    int32_t nprob;
-    int32_t stagger;   // 1: half of the waves of each SIMD issue their LDS-DMA after the first MFMA half-step
-    KProb p[VK_GEMM_MAX_GROUP];
-};
-
-// XOR applied to the 16-byte chunk index of a row of a transposed ([k][cols]) image (low 4 bits only)
-__device__ __forceinline__ int tswz(int row) { return ((row & 3) << 1) ^ (((row >> 3) & 1) << 3); }
 
 // Stage one operand tile of EXT rows (T=false: image [EXT][64 k], 128-B rows) or EXT columns (T=true: image
 // [64 k][EXT], 2*EXT-byte rows) with all THREADS threads; 16-byte chunks, linear LDS image.
@@ -82,29 +63,6 @@ __device__ __forceinline__ void stage_store(uint32_t lds_tile, const u32x4 (&reg
     for (int i = 0; i < NP; ++i) *(u32x4 VK_LDS*)(uintptr_t)(lds_tile + (i * THREADS + tid) * 16) = reg[i];
 }
 
-// fragment for the 16 rows [r0, r0+16) of a K-contiguous image, k-substep ks (32 wide)
-__device__ __forceinline__ bf16x8 frag_rows(uint32_t tile, int r0, int ks, int lane) {
-    const int r = r0 + (lane & 15);
-    const int c = (ks * 4 + (lane >> 4)) ^ (r & 7);
-    return *(const bf16x8 VK_LDS*)(uintptr_t)(tile + r * 128 + c * 16);
-}
-// fragment for the 16 columns [c0, c0+16) of a transposed image ([k][EXT], ROWB bytes per row); natural k order
-template <int ROWB>
-__device__ __forceinline__ bf16x8 frag_cols(uint32_t tile, int c0, int ks, int lane) {
-    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
-    const int row_a = ks * 32 + g * 8 + q;
-    const int chunk = (c0 >> 3) + (p >> 1);
-    const uint32_t a0 = tile + row_a * ROWB + ((chunk ^ tswz(row_a)) << 4) + ((p & 1) << 3);
-    const int row_b = row_a + 4;
-    const uint32_t a1 = tile + row_b * ROWB + ((chunk ^ tswz(row_b)) << 4) + ((p & 1) << 3);
-    bf16x4 lo = lds_read_tr16(a0);
-    bf16x4 hi = lds_read_tr16(a1);
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-}
-
 template <bool AT, bool BT, int EPI, int WM, int WN, bool REGSTAGE, int TM = 1>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const KGroup g) {
     using G = Geo<WM, WN, TM>;
@@ -115,14 +73,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const KGroup g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    // XCD-aware tile order (cdna guide T1): workgroups are dealt round-robin over the 8 XCDs, so give XCD x the
-    // contiguous chunk x of the tile list -- neighbouring tiles (same A row panel) then share one L2.  Bijective for
-    // any grid size; placement only affects speed.
-    int bid = blockIdx.x;
-    {
-        const int nwg = gridDim.x, q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
-    }
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < VK_GEMM_MAX_GROUP; ++i)
@@ -241,80 +192,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const KGroup g) {
         }
     }
 
-    // ---- epilogue: lane owns row m = ...+(lane&15), columns n..n+3 with n = ...+4*(lane>>4) ----
-    const int gq = lane >> 4, lr = lane & 15;
-    const int Mout = AT ? P.M : M;     // TN: M is the output row count and is never dynamic
-    const int N = P.N;
-    constexpr bool F32OUT = (EPI == VK_EPI_F32 || EPI == VK_EPI_F32_ACC);
-    const int nlim = (F32OUT && P.n_store > N) ? P.n_store : N;
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-        const int m = m0 + wm * 64 * TM + i * 16 + lr;
-        if (m >= Mout) continue;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int n = n0 + wn * 64 + j * 16 + gq * 4;
-            if (n >= nlim) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (EPI != VK_EPI_MULR && P.bias) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < N) v[r] += P.bias[n + r];
-            }
-            const size_t off = (size_t)m * P.ldc + n;
-            const bool full = (n + 3 < nlim);
-            if (F32OUT) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r >= N) v[r] = 0.f;
-                float* c = (float*)P.C + off;
-                if (EPI == VK_EPI_F32_ACC) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n + r < nlim) v[r] += c[r];
-                }
-                if (full) *(f32x4*)c = f32x4{v[0], v[1], v[2], v[3]};
-                else
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n + r < nlim) c[r] = v[r];
-                continue;
-            }
-            float w[4] = {0.f, 0.f, 0.f, 0.f};
-            if (EPI == VK_EPI_MULR || EPI == VK_EPI_ADDR) {
-                const uint16_t* rp = (const uint16_t*)P.R + (size_t)m * P.ldr + n;
-                if (full) {
-                    u32x2 rr = *(const u32x2*)rp;
-                    w[0] = bf2f(rr[0] & 0xFFFF); w[1] = bf2f(rr[0] >> 16); w[2] = bf2f(rr[1] & 0xFFFF); w[3] = bf2f(rr[1] >> 16);
-                } else
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n + r < N) w[r] = bf2f(rp[r]);
-            }
-            float o[4], o2[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                if (EPI == VK_EPI_BF16) o[r] = v[r];
-                else if (EPI == VK_EPI_GELU) { gelu_both(v[r], o[r], o2[r]); }
-                else if (EPI == VK_EPI_MULR) o[r] = v[r] * w[r];
-                else if (EPI == VK_EPI_ADDR) o[r] = v[r] + w[r];
-                else o[r] = fmaxf(v[r], 0.f);
-            }
-            uint16_t* c = (uint16_t*)P.C + off;
-            if (full) {
-                *(u32x2*)c = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-                if (EPI == VK_EPI_GELU) *(u32x2*)((uint16_t*)P.C2 + off) = u32x2{pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3])};
-            } else {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < N) {
-                    c[r] = f2bf(o[r]);
-                    if (EPI == VK_EPI_GELU) ((uint16_t*)P.C2 + off)[r] = f2bf(o2[r]);
-                }
-            }
-        }
-    }
-    if (do_bias_grad && gq == 0) {
-#pragma unroll
-        for (int i = 0; i < TI; ++i) {
-            const int m = m0 + wm * 64 * TM + i * 16 + lr;
-            if (m < Mout) P.bias_grad[m] = (EPI == VK_EPI_F32_ACC ? P.bias_grad[m] : 0.f) + accb[i][0];
-        }
-    }
+    gemm_epilogue<AT, EPI, TI, 4>(P, acc, accb, do_bias_grad, m0 + wm * 64 * TM, n0 + wn * 64, M, lane);
 }
 
 template <bool AT, bool BT, int WM, int WN, bool REGSTAGE, int TM = 1>
@@ -337,9 +215,9 @@ static int launch_cfg(int epi, const KGroup& g, int total, hipStream_t s) {
     return check_launch("vk_gemm_grouped");
 }
 
-static int g_tile_override = 0;       // tuning hook: 0 = heuristic, 128 / 192 / 256 = force 128x128 / 256x128 / 256x256
+static int g_tile_override = 0;       // tuning hook: 0 = heuristic, 128 / 256 / 257 = force 128x128 / 256x256 8-phase / legacy 256x256
 static int g_stagger = 1;
-static int g_waves256 = 16;          // waves of the 256x256 geometry: 16 (64x64 each) or 8 (128x64 each)
+static int g_debug = 0;            // ablation switches of the 256 x 256 kernel (gemm256.hip)
 static int g_regstage_override = -1;  // -1 = heuristic, 0 / 1 = force LDS-DMA / register staging (128^2 only)
 
 static int total_tiles(const vk_gemm_problem* probs, int nprob, int epilogue, int bm, int bn) {
@@ -371,16 +249,21 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
         if ((epilogue == VK_EPI_MULR || epilogue == VK_EPI_ADDR) && !q.R) return set_error("vk_gemm_grouped: R missing");
         if (epilogue == VK_EPI_GELU && !q.C2) return set_error("vk_gemm_grouped: C2 missing");
     }
-    // Tile choice: the largest of 256x256 / 256x128 / 128x128 that still yields >= 160 workgroups (256 CUs).
-    // `edge` encodes the geometry: 256 -> 256x256, 192 -> 256x128, 128 -> 128x128.
+    // Tile choice: 256 x 256 whenever that still yields >= 160 workgroups (256 CUs), else 128 x 128.
+    // Tuning hook values: 128, 256, 257 (= the legacy 16-wave 256 x 256 kernel, kept for A/B runs).
     int edge = g_tile_override;
-    if (edge == 0) {
-        edge = total_tiles(probs, nprob, epilogue, 256, 256) >= 160 ? 256 : 128;   // 256x128 never won (profiles/r01_gemm_tiles.txt)
+    if (edge == 0) edge = total_tiles(probs, nprob, epilogue, 256, 256) >= 160 ? 257 : 128;
+    if (edge == 256) {
+        for (int i = 0; i < nprob; ++i) {
+            const vk_gemm_problem& q = probs[i];
+            const uint64_t ea = (uint64_t)(layout == VK_TN ? q.K : q.M) * q.lda * 2, eb = (uint64_t)(layout == VK_NT ? q.N : q.K) * q.ldb * 2;
+            if (ea >= 0x80000000ull || eb >= 0x80000000ull) { edge = 128; break; }     // the 8-phase kernel addresses operands below 2 GiB
+        }
     }
-    const int bm = edge == 128 ? 128 : 256, bn = edge == 256 ? 256 : 128;
+    const int bm = edge == 128 ? 128 : 256, bn = bm;
     KGroup g;
     g.nprob = nprob;
-    g.stagger = g_stagger;
+    g.stagger = g_stagger | (g_debug << 8);
     int total = 0;
     for (int i = 0; i < nprob; ++i) {
         const vk_gemm_problem& q = probs[i];
@@ -395,18 +278,11 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
     }
     if (total == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (edge == 256 && g_waves256 == 8) {      // 256x256 with 8 waves of 128x64 (2 x 4)
-        if (layout == VK_NT) return launch_cfg<false, false, 2, 4, false, 2>(epilogue, g, total, s);
-        if (layout == VK_NN) return launch_cfg<false, true, 2, 4, false, 2>(epilogue, g, total, s);
-        if (layout == VK_TN) return launch_cfg<true, true, 2, 4, false, 2>(epilogue, g, total, s);
-    } else if (edge == 256) {
+    if (edge == 256) return launch_gemm256(layout, epilogue, g, total, s);
+    if (edge == 257) {
         if (layout == VK_NT) return launch_cfg<false, false, 4, 4, false>(epilogue, g, total, s);
         if (layout == VK_NN) return launch_cfg<false, true, 4, 4, false>(epilogue, g, total, s);
         if (layout == VK_TN) return launch_cfg<true, true, 4, 4, false>(epilogue, g, total, s);
-    } else if (edge == 192) {
-        if (layout == VK_NT) return launch_cfg<false, false, 4, 2, false>(epilogue, g, total, s);
-        if (layout == VK_NN) return launch_cfg<false, true, 4, 2, false>(epilogue, g, total, s);
-        if (layout == VK_TN) return launch_cfg<true, true, 4, 2, false>(epilogue, g, total, s);
     } else {
         const bool reg = g_regstage_override >= 0 ? g_regstage_override != 0 : layout != VK_NT;
         if (layout == VK_NT) return reg ? launch_cfg<false, false, 2, 2, true>(epilogue, g, total, s) : launch_cfg<false, false, 2, 2, false>(epilogue, g, total, s);
@@ -420,4 +296,4 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
 extern "C" void vk_gemm_set_tile(int edge) { vk::g_tile_override = edge; }
 extern "C" void vk_gemm_set_regstage(int v) { vk::g_regstage_override = v; }
 extern "C" void vk_gemm_set_stagger(int v) { vk::g_stagger = v; }
-extern "C" void vk_gemm_set_waves256(int v) { vk::g_waves256 = v; }
+extern "C" void vk_gemm_set_debug(int v) { vk::g_debug = v; }

@@ -1,0 +1,248 @@
+// 256 x 256 x 64 bf16 GEMM tile for gfx950: 8 waves (2 along M x 4 along N, 128 x 64 outputs each), 128 KiB of
+// LDS, LDS-DMA staging with counted vmcnt, and a K loop of 4 phases per K-tile in which the two halves of the
+// workgroup run half a phase apart -- on every SIMD one wave multiplies while its partner reads LDS and issues
+// the next DMA (the "8-phase" structure of the CDNA4 guide, section 5).
+//
+// LDS holds 2 K-tiles x 4 half-tiles of 16 KiB.  A half-tile is SUB-TILE-major: it holds, for every wave, the
+// part of the operand that one phase consumes,
+//     A0 / A1 : rows  wr*128 + s*64 + [0,64)   of the 256-row A tile (s = 0 / 1),   image [128][64 k]
+//     B0 / B1 : cols  wc*64  + s*32 + [0,32)   of the 256-col B tile,               image [128][64 k]
+// (transposed operands: image [64 k][128], read with ds_read_b64_tr_b16), so the four half-tiles of a K-tile
+// are needed -- and die -- one phase after another:
+//     phase 1: read B0, A0   acc[0:4][0:2] += A0 B0        phase 3: read A1       acc[4:8][2:4] += A1 B1
+//     phase 2: read B1       acc[0:4][2:4] += A0 B1        phase 4: (registers)   acc[4:8][0:2] += A1 B0
+// Half-tiles are staged in consumption order, index idx = 4*kt + {A0:0, B0:1, B1:2, A1:3}; global phase
+// g = 4*kt + p stages idx g + 5 into the slot of idx g - 3, whose last read was in phase <= g - 2 (WAR: a slot
+// is re-staged >= 2 phases after its last ds_read).  Every wave waits vmcnt(8) after its stage -- the 4 newest
+// half-tiles (2 DMA instructions each) stay in flight, everything up to idx g + 1 has landed -- BEFORE the
+// phase's first barrier, and idx g + 1 is first read in phase g + 1 (RAW: read one phase after the wait).
+// Stages past the end of K are issued with an out-of-range offset (the buffer bounds check turns them into
+// zero fills without memory traffic) so that the vmcnt arithmetic is the same in every iteration.
+#include "gemm_common.h"
+#include <type_traits>
+
+namespace vk {
+
+constexpr uint32_t HT = 16384;          // bytes of one half-tile slot
+constexpr uint32_t OOB = 0x80000000u;   // beyond any operand (host checks extents < 2 GiB)
+
+// Byte offsets (s = 0, kt = 0) of the two 16-byte pieces a thread stages of a half-tile; the XOR swizzle of the
+// LDS image is applied here, on the global source (the LDS-DMA destination is lane-linear).
+template <bool T, bool IS_A>
+__device__ __forceinline__ void stage_offsets(uint32_t (&off)[2], int ld, int ext0, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lin = i * 512 + tid;
+        if (!T) {
+            const int hr = lin >> 3, cp = lin & 7;                       // image row, 16-byte chunk position
+            const int row = IS_A ? ((hr >> 6) * 128 + (hr & 63)) : ((hr >> 5) * 64 + (hr & 31));
+            off[i] = ((uint32_t)(ext0 + row) * (uint32_t)ld + (uint32_t)((cp ^ (hr & 7)) * 8)) * 2u;
+        } else {
+            const int kr = lin >> 4, cp = lin & 15;
+            const int c = cp ^ tswz(kr);
+            const int col = IS_A ? ((c >> 3) * 128 + (c & 7) * 8) : ((c >> 2) * 64 + (c & 3) * 8);
+            off[i] = ((uint32_t)kr * (uint32_t)ld + (uint32_t)(ext0 + col)) * 2u;
+        }
+    }
+}
+
+__device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rs, uint32_t slot, const uint32_t (&off)[2], uint32_t add, int wave) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const uint32_t dst = slot + (i * 512 + wave * 64) * 16;       // wave-uniform; hardware adds lane * 16
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (VK_LDS void*)(uintptr_t)dst, 16, off[i] + add, 0, 0, 0);
+    }
+}
+
+#define VK_SYNC()                                 \
+    do {                                          \
+        __builtin_amdgcn_sched_barrier(0);        \
+        __builtin_amdgcn_s_barrier();             \
+        __builtin_amdgcn_sched_barrier(0);        \
+    } while (0)
+#define VK_WAIT_DMA() asm volatile("s_waitcnt vmcnt(8)" ::: "memory")
+#define VK_WAIT_LDS()                                          \
+    do {                                                       \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     \
+        __builtin_amdgcn_sched_barrier(0);                     \
+    } while (0)
+
+template <int V> using ic = std::integral_constant<int, V>;
+
+template <bool AT, bool BT, int EPI>
+__global__ __launch_bounds__(512) void gemm256_kernel(const KGroup g) {
+    constexpr bool BG = AT && BT;          // bias gradient (column sums of A) rides on the wgrad layout only
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(VK_LDS char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < VK_GEMM_MAX_GROUP; ++i)
+        if (i < g.nprob && bid >= g.p[i].tile_start) pi = i;
+    const KProb& P = g.p[pi];
+    const int t = bid - P.tile_start;
+    const int tm = t / P.tiles_n, tn = t - tm * P.tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    int M = P.M, K = P.K;
+    if (P.dyn) {
+        const int d = *P.dyn;
+        if (AT) K = d < K ? d : K; else M = d < M ? d : M;
+    }
+    if (m0 >= M) return;
+
+    const int a_rows = AT ? K : M, a_cols = AT ? P.lda : K;
+    const int b_rows = BT ? K : P.N, b_cols = BT ? P.ldb : K;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(P.A, a_rows > 0 ? (uint32_t)(((uint32_t)(a_rows - 1) * P.lda + a_cols) * 2u) : 0u);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(P.B, b_rows > 0 ? (uint32_t)(((uint32_t)(b_rows - 1) * P.ldb + b_cols) * 2u) : 0u);
+
+    uint32_t offA[2], offB[2];
+    stage_offsets<AT, true>(offA, P.lda, m0, tid);
+    stage_offsets<BT, false>(offB, P.ldb, n0, tid);
+    const uint32_t sA = AT ? 128u : 128u * (uint32_t)P.lda, kA = AT ? 128u * (uint32_t)P.lda : 128u;   // bytes per sub-tile / K-tile
+    const uint32_t sB = BT ? 64u : 64u * (uint32_t)P.ldb, kB = BT ? 128u * (uint32_t)P.ldb : 128u;
+    const int nk = (K + BK - 1) / BK;
+    const int dbg = g.stagger >> 8;               // ablation switches (tools/bench_gemm.py): 1 no DMA, 2 no MFMA, 4 no LDS reads
+    bool in_loop = false;
+
+    auto stage = [&](auto X_, int kt) {           // X: 0 = A0, 1 = B0, 2 = B1, 3 = A1
+        if ((dbg & 1) && in_loop) return;
+        constexpr int X = decltype(X_)::value;
+        constexpr bool isA = (X == 0 || X == 3);
+        constexpr uint32_t s = (X >= 2) ? 1u : 0u;
+        const uint32_t slot = lds0 + (uint32_t)((kt & 1) * 4 + X) * HT;
+        const bool live = kt < nk;
+        if (isA) stage_half(rsA, slot, offA, live ? s * sA + (uint32_t)kt * kA : OOB, wave);
+        else     stage_half(rsB, slot, offB, live ? s * sB + (uint32_t)kt * kB : OOB, wave);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias_grad = BG && (P.bias_grad != nullptr) && (tn == 0) && (wc == 0);
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (short)0x3F80;
+
+    bf16x8 a[4][2], b0[2][2], b1[2][2];
+    auto load_a = [&](uint32_t slot) {
+        if (dbg & 4) return;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                a[i][ks] = AT ? frag_cols<256>(slot, wr * 64 + i * 16, ks, lane) : frag_rows(slot, wr * 64 + i * 16, ks, lane);
+    };
+    auto load_b = [&](bf16x8 (&b)[2][2], uint32_t slot) {
+        if (dbg & 4) return;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                b[j][ks] = BT ? frag_cols<256>(slot, wc * 32 + j * 16, ks, lane) : frag_rows(slot, wc * 32 + j * 16, ks, lane);
+    };
+    auto quad = [&](auto I0_, auto J0_, const bf16x8 (&b)[2][2], bool with_bias) {
+        constexpr int I0 = decltype(I0_)::value, J0 = decltype(J0_)::value;
+        if (dbg & 2) return;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[I0 + i][J0 + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j][ks], a[i][ks], acc[I0 + i][J0 + j], 0, 0, 0);
+        if (BG && with_bias && do_bias_grad) {
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    accb[I0 + i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i][ks], accb[I0 + i], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // prologue: idx 0..5 in flight, idx 0 and 1 (A0, B0 of K-tile 0) landed
+    stage(ic<0>{}, 0); stage(ic<1>{}, 0); stage(ic<2>{}, 0); stage(ic<3>{}, 0); stage(ic<0>{}, 1); stage(ic<1>{}, 1);
+    VK_WAIT_DMA();
+    VK_SYNC();
+    if (wr == 1) VK_SYNC();        // the upper half of the workgroup runs half a phase behind
+    in_loop = true;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const uint32_t buf = lds0 + (uint32_t)(kt & 1) * 4u * HT;
+        // ---- phase 1
+        load_b(b0, buf + 1 * HT);
+        __builtin_amdgcn_sched_barrier(0);
+        load_a(buf + 0 * HT);
+        stage(ic<2>{}, kt + 1);
+        VK_WAIT_DMA();
+        VK_SYNC();
+        VK_WAIT_LDS();
+        quad(ic<0>{}, ic<0>{}, b0, true);
+        VK_SYNC();
+        // ---- phase 2
+        load_b(b1, buf + 2 * HT);
+        stage(ic<3>{}, kt + 1);
+        VK_WAIT_DMA();
+        VK_SYNC();
+        VK_WAIT_LDS();
+        quad(ic<0>{}, ic<2>{}, b1, false);
+        VK_SYNC();
+        // ---- phase 3
+        load_a(buf + 3 * HT);
+        stage(ic<0>{}, kt + 2);
+        VK_WAIT_DMA();
+        VK_SYNC();
+        VK_WAIT_LDS();
+        quad(ic<4>{}, ic<2>{}, b1, true);
+        VK_SYNC();
+        // ---- phase 4
+        stage(ic<1>{}, kt + 2);
+        VK_WAIT_DMA();
+        VK_SYNC();
+        quad(ic<4>{}, ic<0>{}, b0, false);
+        VK_SYNC();
+    }
+    if (wr == 0) VK_SYNC();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // retire the zero-fill stages issued past the end of K
+
+    gemm_epilogue<AT, EPI, 8, 4>(P, acc, accb, do_bias_grad, m0 + wr * 128, n0 + wc * 64, M, lane);
+}
+
+template <bool AT, bool BT>
+static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s) {
+    constexpr int LDS = 8 * HT;
+#define VK_CASE(E)                                                                                        \
+    case E: {                                                                                             \
+        auto k = gemm256_kernel<AT, BT, E>;                                                               \
+        static bool once = false;                                                                         \
+        if (!once) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; } \
+        hipLaunchKernelGGL(k, dim3(total), dim3(512), LDS, s, g);                                         \
+        break;                                                                                            \
+    }
+    switch (epi) {
+        VK_CASE(VK_EPI_BF16) VK_CASE(VK_EPI_GELU) VK_CASE(VK_EPI_MULR) VK_CASE(VK_EPI_ADDR) VK_CASE(VK_EPI_F32) VK_CASE(VK_EPI_RELU) VK_CASE(VK_EPI_F32_ACC)
+        default: return set_error("vk_gemm_grouped: unknown epilogue %d", epi);
+    }
+#undef VK_CASE
+    return check_launch("vk_gemm_grouped");
+}
+
+int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s) {
+    if (layout == VK_NT) return launch_layout<false, false>(epilogue, g, total, s);
+    if (layout == VK_NN) return launch_layout<false, true>(epilogue, g, total, s);
+    if (layout == VK_TN) return launch_layout<true, true>(epilogue, g, total, s);
+    return set_error("vk_gemm_grouped: unknown layout %d", layout);
+}
+
+}  // namespace vk

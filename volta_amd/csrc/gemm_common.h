@@ -1,0 +1,142 @@
+// Pieces shared by the GEMM kernels of libvolta_hip.so (gemm.hip: 128^2 tiles and the dispatcher,
+// gemm256.hip: the 256^2 8-phase kernel).
+#pragma once
+#include "common.h"
+#include "../../include/volta_hip.h"
+#include "util.h"
+
+namespace vk {
+
+constexpr int BK = 64;
+
+struct KProb {
+    const char* A; const char* B; char* C; char* C2; const float* bias; const char* R; float* bias_grad;
+    const int32_t* dyn;
+    int32_t M, N, K, lda, ldb, ldc, ldr, n_store;
+    int32_t tiles_n, tile_start;
+};
+struct KGroup {
+    int32_t nprob;
+    int32_t stagger;   // 128^2 / legacy geometries: half of the waves of each SIMD issue their LDS-DMA late
+    KProb p[VK_GEMM_MAX_GROUP];
+};
+
+// XOR applied to the 16-byte chunk index of a row of a transposed ([k][cols]) image (low 4 bits only)
+__device__ __forceinline__ int tswz(int row) { return ((row & 3) << 1) ^ (((row >> 3) & 1) << 3); }
+
+// fragment for the 16 rows [r0, r0+16) of a K-contiguous image (128-byte rows), k-substep ks (32 wide)
+__device__ __forceinline__ bf16x8 frag_rows(uint32_t tile, int r0, int ks, int lane) {
+    const int r = r0 + (lane & 15);
+    const int c = (ks * 4 + (lane >> 4)) ^ (r & 7);
+    return *(const bf16x8 VK_LDS*)(uintptr_t)(tile + r * 128 + c * 16);
+}
+// fragment for the 16 columns [c0, c0+16) of a transposed image ([k][EXT], ROWB bytes per row); natural k order
+template <int ROWB>
+__device__ __forceinline__ bf16x8 frag_cols(uint32_t tile, int c0, int ks, int lane) {
+    const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
+    const int row_a = ks * 32 + g * 8 + q;
+    const int chunk = (c0 >> 3) + (p >> 1);
+    const uint32_t a0 = tile + row_a * ROWB + ((chunk ^ tswz(row_a)) << 4) + ((p & 1) << 3);
+    const int row_b = row_a + 4;
+    const uint32_t a1 = tile + row_b * ROWB + ((chunk ^ tswz(row_b)) << 4) + ((p & 1) << 3);
+    bf16x4 lo = lds_read_tr16(a0);
+    bf16x4 hi = lds_read_tr16(a1);
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+}
+
+// XCD-aware tile order (cdna guide T1): workgroups are dealt round-robin over the 8 XCDs, so give XCD x the
+// contiguous chunk x of the tile list -- neighbouring tiles (same A row panel) then share one L2.  Bijective for
+// any grid size; placement only affects speed.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, k = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+// Epilogue shared by every geometry.  acc[i][j] is the 16 x 16 MFMA tile at rows m_base + 16 i, columns
+// n_base + 16 j; with the swapped operands (D = B-frag x A-frag) a lane owns row (lane & 15) and the 4 consecutive
+// columns 4 * (lane >> 4) .. +3 of each tile: 8-byte bf16 / 16-byte fp32 stores.
+template <bool AT, int EPI, int TI, int TJ>
+__device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][TJ], f32x4 (&accb)[TI], bool do_bias_grad,
+                                              int m_base, int n_base, int M, int lane) {
+    const int gq = lane >> 4, lr = lane & 15;
+    const int Mout = AT ? P.M : M;     // TN: M is the output row count and is never dynamic
+    const int N = P.N;
+    constexpr bool F32OUT = (EPI == VK_EPI_F32 || EPI == VK_EPI_F32_ACC);
+    const int nlim = (F32OUT && P.n_store > N) ? P.n_store : N;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+        const int m = m_base + i * 16 + lr;
+        if (m >= Mout) continue;
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) {
+            const int n = n_base + j * 16 + gq * 4;
+            if (n >= nlim) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (EPI != VK_EPI_MULR && P.bias) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < N) v[r] += P.bias[n + r];
+            }
+            const size_t off = (size_t)m * P.ldc + n;
+            const bool full = (n + 3 < nlim);
+            if (F32OUT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r >= N) v[r] = 0.f;
+                float* c = (float*)P.C + off;
+                if (EPI == VK_EPI_F32_ACC) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < nlim) v[r] += c[r];
+                }
+                if (full) *(f32x4*)c = f32x4{v[0], v[1], v[2], v[3]};
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < nlim) c[r] = v[r];
+                continue;
+            }
+            float w[4] = {0.f, 0.f, 0.f, 0.f};
+            if (EPI == VK_EPI_MULR || EPI == VK_EPI_ADDR) {
+                const uint16_t* rp = (const uint16_t*)P.R + (size_t)m * P.ldr + n;
+                if (full) {
+                    u32x2 rr = *(const u32x2*)rp;
+                    w[0] = bf2f(rr[0] & 0xFFFF); w[1] = bf2f(rr[0] >> 16); w[2] = bf2f(rr[1] & 0xFFFF); w[3] = bf2f(rr[1] >> 16);
+                } else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < N) w[r] = bf2f(rp[r]);
+            }
+            float o[4], o2[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                if (EPI == VK_EPI_BF16) o[r] = v[r];
+                else if (EPI == VK_EPI_GELU) { gelu_both(v[r], o[r], o2[r]); }
+                else if (EPI == VK_EPI_MULR) o[r] = v[r] * w[r];
+                else if (EPI == VK_EPI_ADDR) o[r] = v[r] + w[r];
+                else o[r] = fmaxf(v[r], 0.f);
+            }
+            uint16_t* c = (uint16_t*)P.C + off;
+            if (full) {
+                *(u32x2*)c = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                if (EPI == VK_EPI_GELU) *(u32x2*)((uint16_t*)P.C2 + off) = u32x2{pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3])};
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) if (n + r < N) {
+                    c[r] = f2bf(o[r]);
+                    if (EPI == VK_EPI_GELU) ((uint16_t*)P.C2 + off)[r] = f2bf(o2[r]);
+                }
+            }
+        }
+    }
+    if (do_bias_grad && gq == 0) {
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int m = m_base + i * 16 + lr;
+            if (m < Mout) P.bias_grad[m] = (EPI == VK_EPI_F32_ACC ? P.bias_grad[m] : 0.f) + accb[i][0];
+        }
+    }
+}
+
+// 256 x 256 tile, 8 waves, 8-phase LDS-DMA pipeline (gemm256.hip)
+int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s);
+
+}  // namespace vk
