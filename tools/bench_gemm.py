@@ -18,13 +18,16 @@ def bench(name, layout, epi, M, N, K, iters=20):
     C2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16) if epi == L.EPI_GELU else None
     bias = torch.zeros(N, device="cuda")
     p = ops.gemm_problem(A, B, Cb, layout, M, N, K, bias=bias, C2=C2)
-    for _ in range(3):
-        ops.gemm_grouped(layout, epi, [p])
+    import ctypes
+    arr = (L.GemmProblem * 1)(p)
+    rep = L.lib.vk_gemm_repeat          # launches issued back-to-back from native code (no interpreter time between kernels)
+    rep.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    st = ops.stream_ptr()
+    assert rep(layout, epi, arr, 1, 3, st) == 0, L.lib.vk_last_error()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(iters):
-        ops.gemm_grouped(layout, epi, [p])
+    assert rep(layout, epi, arr, 1, iters, st) == 0
     e1.record()
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / iters
@@ -35,7 +38,7 @@ def sweep():
     """A/B of the tile geometries in one process: 128 x 128, 256 x 256 8-phase, legacy 16-wave 256 x 256."""
     import ctypes
     L.lib.vk_gemm_set_tile.argtypes = [ctypes.c_int]
-    for edge in (256, 257, 128, 256):
+    for edge in (258, 256, 257, 258):
         L.lib.vk_gemm_set_tile(edge)
         print("=== tile", edge, flush=True)
         for Mrows, tag in ((5120, "text"), (9472, "vis")):
@@ -58,7 +61,7 @@ def ablate():
     import ctypes
     L.lib.vk_gemm_set_tile.argtypes = [ctypes.c_int]
     L.lib.vk_gemm_set_debug.argtypes = [ctypes.c_int]
-    L.lib.vk_gemm_set_tile(256)
+    L.lib.vk_gemm_set_tile(int(sys.argv[2]) if len(sys.argv) > 2 else 256)
     for dbg, tag in ((0, "full"), (1, "no DMA in loop"), (2, "no MFMA"), (4, "no LDS reads"), (3, "no DMA, no MFMA"), (5, "no DMA, no LDS reads"), (6, "no MFMA, no LDS reads"), (7, "barriers only"), (0, "full")):
         L.lib.vk_gemm_set_debug(dbg)
         print("=== ablation:", tag, flush=True)

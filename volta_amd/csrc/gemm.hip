@@ -64,7 +64,8 @@ __device__ __forceinline__ void stage_store(uint32_t lds_tile, const u32x4 (&reg
 }
 
 template <bool AT, bool BT, int EPI, int WM, int WN, bool REGSTAGE, int TM = 1>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_kernel(const KGroup g) {
+__global__ __launch_bounds__(64 * WM * WN) __attribute__((amdgpu_waves_per_eu(WM * WN == 4 ? (REGSTAGE ? 2 : 3) : 1)))
+void gemm_kernel(const KGroup g) {
     using G = Geo<WM, WN, TM>;
     constexpr int TI = 4 * TM;            // 16-row MFMA tiles per wave along M
     constexpr int THREADS = G::THREADS, BM = G::BM, BN = G::BN;
@@ -253,7 +254,7 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
     // Tuning hook values: 128, 256, 257 (= the legacy 16-wave 256 x 256 kernel, kept for A/B runs).
     int edge = g_tile_override;
     if (edge == 0) edge = total_tiles(probs, nprob, epilogue, 256, 256) >= 160 ? 257 : 128;
-    if (edge == 256) {
+    if (edge == 256 || edge == 258) {
         for (int i = 0; i < nprob; ++i) {
             const vk_gemm_problem& q = probs[i];
             const uint64_t ea = (uint64_t)(layout == VK_TN ? q.K : q.M) * q.lda * 2, eb = (uint64_t)(layout == VK_NT ? q.N : q.K) * q.ldb * 2;
@@ -278,7 +279,7 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
     }
     if (total == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (edge == 256) return launch_gemm256(layout, epilogue, g, total, s);
+    if (edge == 256 || edge == 258) return launch_gemm256(layout, epilogue, g, total, s, edge == 258);
     if (edge == 257) {
         if (layout == VK_NT) return launch_cfg<false, false, 4, 4, false>(epilogue, g, total, s);
         if (layout == VK_NN) return launch_cfg<false, true, 4, 4, false>(epilogue, g, total, s);
@@ -293,6 +294,13 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
 }
 
 /* tuning hooks for tools/bench_gemm.py (0 / -1 restore the heuristics) */
+extern "C" int vk_gemm_repeat(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, int iters, vk_stream_t stream) {
+    for (int i = 0; i < iters; ++i) {       // back-to-back launches from native code: no interpreter time between kernels
+        const int rc = vk_gemm_grouped(layout, epilogue, probs, nprob, stream);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
 extern "C" void vk_gemm_set_tile(int edge) { vk::g_tile_override = edge; }
 extern "C" void vk_gemm_set_regstage(int v) { vk::g_regstage_override = v; }
 extern "C" void vk_gemm_set_stagger(int v) { vk::g_stagger = v; }

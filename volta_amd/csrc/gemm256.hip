@@ -219,12 +219,150 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const KGroup g) {
     gemm_epilogue<AT, EPI, 8, 4>(P, acc, accb, do_bias_grad, m0 + wr * 128, n0 + wc * 64, M, lane);
 }
 
-template <bool AT, bool BT>
+
+// ---------------------------------------------------------------------------------------------------------
+// Variant B: one phase per 32-deep K-step.  Every phase reads the whole wave tile's fragments (8 A + 4 B,
+// 12 ds_read_b128), issues the DMA of one K-step (A and B strips of 256 x 32, 16 KiB each, 4 instructions per
+// wave) and runs 32 MFMAs -- half the barriers of the 4-phase loop and the same LDS work in every phase.
+// LDS is a ring of 5 K-steps (160 KiB).  Phase P stages K-step P + 3 into the slot K-step P - 2 was read from
+// (WAR: >= 2 phases after its last ds_read) and waits vmcnt(8): K-steps P + 2 and P + 3 stay in flight, K-step
+// P + 1 has landed and is first read one phase later (RAW).
+// Strip image, K-contiguous operand: [256 rows][32 k], 64-byte rows, 16-byte chunk c of row r stored at chunk
+// c ^ f(r), f(r) = (-(r >> 2)) & 3 -- with that every 16-lane group of a ds_read_b128 covers the 16 slots of
+// a 256-byte bank row once.  Transposed operand: [32 k][256], 512-byte rows, read with ds_read_b64_tr_b16.
+__device__ __forceinline__ int kswz(int r) { return (-(r >> 2)) & 3; }
+
+template <bool T>
+__device__ __forceinline__ void strip_offsets(uint32_t (&off)[2], int ld, int ext0, int tid) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int lin = i * 512 + tid;
+        if (!T) {
+            const int r = lin >> 2, cp = lin & 3;
+            off[i] = ((uint32_t)(ext0 + r) * (uint32_t)ld + (uint32_t)((cp ^ kswz(r)) * 8)) * 2u;
+        } else {
+            const int kr = lin >> 5, cp = lin & 31;
+            off[i] = ((uint32_t)kr * (uint32_t)ld + (uint32_t)(ext0 + (cp ^ tswz(kr)) * 8)) * 2u;
+        }
+    }
+}
+
+__device__ __forceinline__ bf16x8 frag_strip(uint32_t strip, int r0, int lane) {
+    const int r = r0 + (lane & 15);
+    return *(const bf16x8 VK_LDS*)(uintptr_t)(strip + r * 64 + (((lane >> 4) ^ kswz(r)) << 4));
+}
+
+template <bool AT, bool BT, int EPI>
+__global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
+    constexpr bool BG = AT && BT;
+    constexpr int RING = 5;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(VK_LDS char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < VK_GEMM_MAX_GROUP; ++i)
+        if (i < g.nprob && bid >= g.p[i].tile_start) pi = i;
+    const KProb& P = g.p[pi];
+    const int t = bid - P.tile_start;
+    const int tm = t / P.tiles_n, tn = t - tm * P.tiles_n;
+    const int m0 = tm * 256, n0 = tn * 256;
+
+    int M = P.M, K = P.K;
+    if (P.dyn) {
+        const int d = *P.dyn;
+        if (AT) K = d < K ? d : K; else M = d < M ? d : M;
+    }
+    if (m0 >= M) return;
+
+    const int a_rows = AT ? K : M, a_cols = AT ? P.lda : K;
+    const int b_rows = BT ? K : P.N, b_cols = BT ? P.ldb : K;
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(P.A, a_rows > 0 ? (uint32_t)(((uint32_t)(a_rows - 1) * P.lda + a_cols) * 2u) : 0u);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(P.B, b_rows > 0 ? (uint32_t)(((uint32_t)(b_rows - 1) * P.ldb + b_cols) * 2u) : 0u);
+
+    uint32_t offA[2], offB[2];
+    strip_offsets<AT>(offA, P.lda, m0, tid);
+    strip_offsets<BT>(offB, P.ldb, n0, tid);
+    const uint32_t kA = AT ? 64u * (uint32_t)P.lda : 64u, kB = BT ? 64u * (uint32_t)P.ldb : 64u;     // bytes per 32-deep K-step
+    const int np = (K + 31) / 32;
+    const int dbg = g.stagger >> 8;
+    bool in_loop = false;
+
+    auto stage = [&](int p, int slot) {
+        if ((dbg & 1) && in_loop) return;
+        const bool live = p < np;
+        const uint32_t sa = lds0 + (uint32_t)slot * 2u * HT;
+        stage_half(rsA, sa, offA, live ? (uint32_t)p * kA : OOB, wave);
+        stage_half(rsB, sa + HT, offB, live ? (uint32_t)p * kB : OOB, wave);
+    };
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accb[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias_grad = BG && (P.bias_grad != nullptr) && (tn == 0) && (wc == 0);
+    bf16x8 ones;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ones[i] = (short)0x3F80;
+
+    stage(0, 0); stage(1, 1); stage(2, 2);
+    VK_WAIT_DMA();
+    VK_SYNC();
+    if (wr == 1) VK_SYNC();        // the upper half of the workgroup runs half a phase behind
+    in_loop = true;
+
+    int rd = 0, wrs = 3;           // ring slots of the K-step read / staged in this phase
+    for (int p = 0; p < np; ++p) {
+        const uint32_t sa = lds0 + (uint32_t)rd * 2u * HT, sb = sa + HT;
+        bf16x8 a[8], b[4];
+        if (!(dbg & 4)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = BT ? frag_cols<512>(sb, wc * 64 + j * 16, 0, lane) : frag_strip(sb, wc * 64 + j * 16, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = AT ? frag_cols<512>(sa, wr * 128 + i * 16, 0, lane) : frag_strip(sa, wr * 128 + i * 16, lane);
+        }
+        stage(p + 3, wrs);
+        VK_WAIT_DMA();
+        VK_SYNC();
+        VK_WAIT_LDS();
+        if (!(dbg & 2)) {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            if (BG && do_bias_grad) {
+#pragma unroll
+                for (int i = 0; i < 8; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i], accb[i], 0, 0, 0);
+            }
+            __builtin_amdgcn_s_setprio(0);
+        }
+        VK_SYNC();
+        rd = rd == RING - 1 ? 0 : rd + 1;
+        wrs = wrs == RING - 1 ? 0 : wrs + 1;
+    }
+    if (wr == 0) VK_SYNC();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    gemm_epilogue<AT, EPI, 8, 4>(P, acc, accb, do_bias_grad, m0 + wr * 128, n0 + wc * 64, M, lane);
+}
+
+template <bool AT, bool BT, bool KSPLIT>
 static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s) {
-    constexpr int LDS = 8 * HT;
+    constexpr int LDS = (KSPLIT ? 10 : 8) * HT;
 #define VK_CASE(E)                                                                                        \
     case E: {                                                                                             \
-        auto k = gemm256_kernel<AT, BT, E>;                                                               \
+        auto k = KSPLIT ? gemm256k_kernel<AT, BT, E> : gemm256_kernel<AT, BT, E>;                         \
         static bool once = false;                                                                         \
         if (!once) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; } \
         hipLaunchKernelGGL(k, dim3(total), dim3(512), LDS, s, g);                                         \
@@ -238,10 +376,15 @@ static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s) {
     return check_launch("vk_gemm_grouped");
 }
 
-int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s) {
-    if (layout == VK_NT) return launch_layout<false, false>(epilogue, g, total, s);
-    if (layout == VK_NN) return launch_layout<false, true>(epilogue, g, total, s);
-    if (layout == VK_TN) return launch_layout<true, true>(epilogue, g, total, s);
+int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, bool ksplit) {
+    if (ksplit) {
+        if (layout == VK_NT) return launch_layout<false, false, true>(epilogue, g, total, s);
+        if (layout == VK_NN) return launch_layout<false, true, true>(epilogue, g, total, s);
+        if (layout == VK_TN) return launch_layout<true, true, true>(epilogue, g, total, s);
+    }
+    if (layout == VK_NT) return launch_layout<false, false, false>(epilogue, g, total, s);
+    if (layout == VK_NN) return launch_layout<false, true, false>(epilogue, g, total, s);
+    if (layout == VK_TN) return launch_layout<true, true, false>(epilogue, g, total, s);
     return set_error("vk_gemm_grouped: unknown layout %d", layout);
 }
 

@@ -58,6 +58,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // Epilogue shared by every geometry.  acc[i][j] is the 16 x 16 MFMA tile at rows m_base + 16 i, columns
 // n_base + 16 j; with the swapped operands (D = B-frag x A-frag) a lane owns row (lane & 15) and the 4 consecutive
 // columns 4 * (lane >> 4) .. +3 of each tile: 8-byte bf16 / 16-byte fp32 stores.
+// Every global READ of the epilogue (bias, residual / multiplier R, accumulate-into C) is an unconditional
+// bounds-checked buffer load -- absent operands and out-of-range rows / columns read as 0 -- so the compiler can
+// issue them all up front instead of one dependent L2 round trip per element; only the stores are predicated.
 template <bool AT, int EPI, int TI, int TJ>
 __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][TJ], f32x4 (&accb)[TI], bool do_bias_grad,
                                               int m_base, int n_base, int M, int lane) {
@@ -65,30 +68,64 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
     const int Mout = AT ? P.M : M;     // TN: M is the output row count and is never dynamic
     const int N = P.N;
     constexpr bool F32OUT = (EPI == VK_EPI_F32 || EPI == VK_EPI_F32_ACC);
+    constexpr bool USE_R = (EPI == VK_EPI_MULR || EPI == VK_EPI_ADDR);
     const int nlim = (F32OUT && P.n_store > N) ? P.n_store : N;
+
+    float bv[TJ][4];
+    {
+        const bool has_bias = (EPI != VK_EPI_MULR) && (P.bias != nullptr);
+        const __amdgpu_buffer_rsrc_t rb = make_rsrc(P.bias, has_bias ? (uint32_t)N * 4u : 0u);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                bv[j][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, (uint32_t)(n_base + j * 16 + gq * 4 + r) * 4u, 0, 0));
+    }
+    const __amdgpu_buffer_rsrc_t rr = make_rsrc(P.R, (USE_R && Mout > 0) ? (uint32_t)(((uint32_t)(Mout - 1) * P.ldr + N) * 2u) : 0u);
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(P.C, (EPI == VK_EPI_F32_ACC && Mout > 0) ? (uint32_t)(((uint32_t)(Mout - 1) * P.ldc + nlim) * 4u) : 0u);
+
 #pragma unroll
     for (int i = 0; i < TI; ++i) {
+        __builtin_amdgcn_sched_barrier(0);     // one row of tiles at a time: keeps the epilogue's live registers below the K loop's
         const int m = m_base + i * 16 + lr;
-        if (m >= Mout) continue;
+        const bool row_ok = m < Mout;
+        u32x2 rv[TJ];
+        u32x4 cv[TJ];
+        if (USE_R) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int n = n_base + j * 16 + gq * 4;
+                const uint32_t off = (row_ok && n < N) ? ((uint32_t)m * (uint32_t)P.ldr + (uint32_t)n) * 2u : 0xFFFFFFF0u;
+                rv[j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(rr, off, 0, 0));
+            }
+        }
+        if (EPI == VK_EPI_F32_ACC) {
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                const int n = n_base + j * 16 + gq * 4;
+                const uint32_t off = (row_ok && n < nlim) ? ((uint32_t)m * (uint32_t)P.ldc + (uint32_t)n) * 4u : 0xFFFFFFF0u;
+                if (n + 3 < nlim || !row_ok) cv[j] = __builtin_amdgcn_raw_buffer_load_b128(rc, off, 0, 0);
+                else {                                     // ragged last columns: per-dword bounds
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) cv[j][r] = (n + r < nlim) ? __builtin_amdgcn_raw_buffer_load_b32(rc, off + 4u * r, 0, 0) : 0u;
+                }
+            }
+        }
 #pragma unroll
         for (int j = 0; j < TJ; ++j) {
             const int n = n_base + j * 16 + gq * 4;
-            if (n >= nlim) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (EPI != VK_EPI_MULR && P.bias) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) if (n + r < N) v[r] += P.bias[n + r];
-            }
+            float v[4] = {acc[i][j][0] + bv[j][0], acc[i][j][1] + bv[j][1], acc[i][j][2] + bv[j][2], acc[i][j][3] + bv[j][3]};
             const size_t off = (size_t)m * P.ldc + n;
             const bool full = (n + 3 < nlim);
             if (F32OUT) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) if (n + r >= N) v[r] = 0.f;
-                float* c = (float*)P.C + off;
                 if (EPI == VK_EPI_F32_ACC) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n + r < nlim) v[r] += c[r];
+                    for (int r = 0; r < 4; ++r) v[r] += __builtin_bit_cast(float, cv[j][r]);
                 }
+                if (!row_ok || n >= nlim) continue;
+                float* c = (float*)P.C + off;
                 if (full) *(f32x4*)c = f32x4{v[0], v[1], v[2], v[3]};
                 else
 #pragma unroll
@@ -96,15 +133,7 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
                 continue;
             }
             float w[4] = {0.f, 0.f, 0.f, 0.f};
-            if (EPI == VK_EPI_MULR || EPI == VK_EPI_ADDR) {
-                const uint16_t* rp = (const uint16_t*)P.R + (size_t)m * P.ldr + n;
-                if (full) {
-                    u32x2 rr = *(const u32x2*)rp;
-                    w[0] = bf2f(rr[0] & 0xFFFF); w[1] = bf2f(rr[0] >> 16); w[2] = bf2f(rr[1] & 0xFFFF); w[3] = bf2f(rr[1] >> 16);
-                } else
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) if (n + r < N) w[r] = bf2f(rp[r]);
-            }
+            if (USE_R) { w[0] = bf2f(rv[j][0] & 0xFFFF); w[1] = bf2f(rv[j][0] >> 16); w[2] = bf2f(rv[j][1] & 0xFFFF); w[3] = bf2f(rv[j][1] >> 16); }
             float o[4], o2[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -114,6 +143,7 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
                 else if (EPI == VK_EPI_ADDR) o[r] = v[r] + w[r];
                 else o[r] = fmaxf(v[r], 0.f);
             }
+            if (!row_ok || n >= nlim) continue;
             uint16_t* c = (uint16_t*)P.C + off;
             if (full) {
                 *(u32x2*)c = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
@@ -137,6 +167,6 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
 }
 
 // 256 x 256 tile, 8 waves, 8-phase LDS-DMA pipeline (gemm256.hip)
-int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s);
+int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, bool ksplit);
 
 }  // namespace vk
