@@ -62,7 +62,7 @@ def ablate():
     L.lib.vk_gemm_set_tile.argtypes = [ctypes.c_int]
     L.lib.vk_gemm_set_debug.argtypes = [ctypes.c_int]
     L.lib.vk_gemm_set_tile(int(sys.argv[2]) if len(sys.argv) > 2 else 256)
-    for dbg, tag in ((0, "full"), (1, "no DMA in loop"), (2, "no MFMA"), (4, "no LDS reads"), (3, "no DMA, no MFMA"), (5, "no DMA, no LDS reads"), (6, "no MFMA, no LDS reads"), (7, "barriers only"), (0, "full")):
+    for dbg, tag in ((0, "full"), (1, "no DMA in loop"), (2, "no MFMA"), (4, "no LDS reads"), (3, "no DMA, no MFMA"), (5, "no DMA, no LDS reads"), (6, "no MFMA, no LDS reads"), (7, "barriers only"), (16, "exit at once"), (7 + 32, "no K loop"), (7 + 32 + 8, "no K loop, no epilogue"), (7 + 8, "barriers only, no epilogue"), (8, "no epilogue"), (0, "full")):
         L.lib.vk_gemm_set_debug(dbg)
         print("=== ablation:", tag, flush=True)
         bench("text qkv fwd NT", L.NT, L.EPI_BF16, 5120, 2304, 768)

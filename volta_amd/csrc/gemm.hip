@@ -19,6 +19,7 @@
 // Replaces every nn.Linear forward/backward of volta/encoders.py and volta/embeddings.py
 // (site list in include/volta_hip.h).
 #include "gemm_common.h"
+#include <cstdlib>
 
 namespace vk {
 
@@ -218,6 +219,7 @@ static int launch_cfg(int epi, const KGroup& g, int total, hipStream_t s) {
 
 static int g_tile_override = 0;       // tuning hook: 0 = heuristic, 128 / 256 / 257 = force 128x128 / 256x256 8-phase / legacy 256x256
 static int g_stagger = 1;
+static int g_min_tiles256 = 160;   // fewest 256 x 256 tiles for which that geometry is chosen (256 CUs)
 static int g_debug = 0;            // ablation switches of the 256 x 256 kernel (gemm256.hip)
 static int g_regstage_override = -1;  // -1 = heuristic, 0 / 1 = force LDS-DMA / register staging (128^2 only)
 
@@ -252,8 +254,14 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
     }
     // Tile choice: 256 x 256 whenever that still yields >= 160 workgroups (256 CUs), else 128 x 128.
     // Tuning hook values: 128, 256, 257 (= the legacy 16-wave 256 x 256 kernel, kept for A/B runs).
+    static const bool env_once = [] {       // tuning overrides from the environment (tools only; unset in production)
+        if (const char* e = getenv("VK_GEMM_MIN_TILES256")) g_min_tiles256 = atoi(e);
+        if (const char* e = getenv("VK_GEMM_TILE")) g_tile_override = atoi(e);
+        return true;
+    }();
+    (void)env_once;
     int edge = g_tile_override;
-    if (edge == 0) edge = total_tiles(probs, nprob, epilogue, 256, 256) >= 160 ? 257 : 128;
+    if (edge == 0) edge = total_tiles(probs, nprob, epilogue, 256, 256) >= g_min_tiles256 ? 258 : 128;
     if (edge == 256 || edge == 258) {
         for (int i = 0; i < nprob; ++i) {
             const vk_gemm_problem& q = probs[i];
@@ -305,3 +313,4 @@ extern "C" void vk_gemm_set_tile(int edge) { vk::g_tile_override = edge; }
 extern "C" void vk_gemm_set_regstage(int v) { vk::g_regstage_override = v; }
 extern "C" void vk_gemm_set_stagger(int v) { vk::g_stagger = v; }
 extern "C" void vk_gemm_set_debug(int v) { vk::g_debug = v; }
+extern "C" void vk_gemm_set_min_tiles256(int v) { vk::g_min_tiles256 = v; }

@@ -106,8 +106,9 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const KGroup g) {
     const uint32_t sA = AT ? 128u : 128u * (uint32_t)P.lda, kA = AT ? 128u * (uint32_t)P.lda : 128u;   // bytes per sub-tile / K-tile
     const uint32_t sB = BT ? 64u : 64u * (uint32_t)P.ldb, kB = BT ? 128u * (uint32_t)P.ldb : 128u;
     const int nk = (K + BK - 1) / BK;
-    const int dbg = g.stagger >> 8;               // ablation switches (tools/bench_gemm.py): 1 no DMA, 2 no MFMA, 4 no LDS reads
+    const int dbg = g.stagger >> 8;               // ablation switches (tools/bench_gemm.py): 1 no DMA, 2 no MFMA, 4 no LDS reads, 8 no epilogue, 16 exit at once, 32 no K loop
     bool in_loop = false;
+    if (dbg & 16) return;
 
     auto stage = [&](auto X_, int kt) {           // X: 0 = A0, 1 = B0, 2 = B1, 3 = A1
         if ((dbg & 1) && in_loop) return;
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const KGroup g) {
     if (wr == 1) VK_SYNC();        // the upper half of the workgroup runs half a phase behind
     in_loop = true;
 
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = 0; kt < ((dbg & 32) ? 0 : nk); ++kt) {
         const uint32_t buf = lds0 + (uint32_t)(kt & 1) * 4u * HT;
         // ---- phase 1
         load_b(b0, buf + 1 * HT);
@@ -215,8 +216,10 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const KGroup g) {
     }
     if (wr == 0) VK_SYNC();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // retire the zero-fill stages issued past the end of K
+    if (dbg & 8) return;
+    VK_SYNC();                                            // ... of every wave: LDS is now free for the epilogue's transposition
 
-    gemm_epilogue<AT, EPI, 8, 4>(P, acc, accb, do_bias_grad, m0 + wr * 128, n0 + wc * 64, M, lane);
+    gemm_epilogue<AT, EPI, 8, 4>(P, acc, accb, do_bias_grad, m0 + wr * 128, n0 + wc * 64, M, lane, lds0 + (uint32_t)wave * 16384u);
 }
 
 
@@ -353,8 +356,9 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
     }
     if (wr == 0) VK_SYNC();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    VK_SYNC();
 
-    gemm_epilogue<AT, EPI, 8, 4>(P, acc, accb, do_bias_grad, m0 + wr * 128, n0 + wc * 64, M, lane);
+    gemm_epilogue<AT, EPI, 8, 4>(P, acc, accb, do_bias_grad, m0 + wr * 128, n0 + wc * 64, M, lane, lds0 + (uint32_t)wave * 16384u);
 }
 
 template <bool AT, bool BT, bool KSPLIT>

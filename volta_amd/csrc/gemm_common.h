@@ -63,13 +63,111 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // issue them all up front instead of one dependent L2 round trip per element; only the stores are predicated.
 template <bool AT, int EPI, int TI, int TJ>
 __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][TJ], f32x4 (&accb)[TI], bool do_bias_grad,
-                                              int m_base, int n_base, int M, int lane) {
+                                              int m_base, int n_base, int M, int lane, uint32_t lds_region = 0) {
     const int gq = lane >> 4, lr = lane & 15;
     const int Mout = AT ? P.M : M;     // TN: M is the output row count and is never dynamic
     const int N = P.N;
     constexpr bool F32OUT = (EPI == VK_EPI_F32 || EPI == VK_EPI_F32_ACC);
     constexpr bool USE_R = (EPI == VK_EPI_MULR || EPI == VK_EPI_ADDR);
     const int nlim = (F32OUT && P.n_store > N) ? P.n_store : N;
+
+    // Fast path: the wave's whole TI x TJ block of tiles lies inside the output -- straight-line code, no predicates.
+    // With a wave-private 16 KiB LDS region the results are written as full rows: the MFMA layout gives a store
+    // instruction 16 rows x 32 (64) bytes, which measured 5x below the write rate of a plain fill; staged through an
+    // XOR-swizzled LDS image every store instruction covers whole 128-byte lines (8 / 4 rows x 128 / 256 bytes).
+    if (m_base + 16 * TI <= Mout && n_base + 16 * TJ <= N) {
+        char* const Cp = P.C;
+        char* const C2p = P.C2;
+        const char* const Rp = P.R;
+        const int ldc = P.ldc, ldr = P.ldr;
+        constexpr int ES = F32OUT ? 4 : 2;                     // bytes per output element
+        constexpr int ROWB = TJ * 16 * ES;                     // bytes per image row
+        constexpr int NIMG = (EPI == VK_EPI_GELU) ? 2 : 1;
+        constexpr int RPH0 = 16384 / (ROWB * NIMG);            // rows per pass through the 16 KiB region
+        constexpr int RPH = RPH0 < TI * 16 ? RPH0 : TI * 16;
+        constexpr int TIH = RPH / 16;                          // row tiles per pass
+        constexpr int CPR = ROWB / 16;                         // 16-byte chunks per row
+        constexpr int RPI = 64 / CPR;                          // rows per store instruction
+        const bool via_lds = lds_region != 0 && ((ldc * ES) & 15) == 0 && (((uintptr_t)Cp | (uintptr_t)C2p) & 15) == 0;
+        const uint32_t img2 = lds_region + RPH * ROWB;
+        f32x4 b4[TJ];
+        {
+            const bool has_bias = (EPI != VK_EPI_MULR) && (P.bias != nullptr);
+            const __amdgpu_buffer_rsrc_t rb = make_rsrc(P.bias, has_bias ? (uint32_t)N * 4u : 0u);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                b4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (uint32_t)(n_base + j * 16 + gq * 4) * 4u, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            __builtin_amdgcn_sched_barrier(0);
+            const int m = m_base + i * 16 + lr;
+            const int lrow = (i % TIH) * 16 + lr;              // row inside the LDS image
+            const size_t rowc = (size_t)m * ldc + (size_t)(n_base + gq * 4);
+            u32x2 rv[TJ];
+            f32x4 cv[TJ];
+            if (USE_R) {
+                const char* rrow = Rp + ((size_t)m * ldr + (size_t)(n_base + gq * 4)) * 2;
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) rv[j] = *(const u32x2*)(rrow + j * 32);
+            }
+            if (EPI == VK_EPI_F32_ACC) {
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) cv[j] = *(const f32x4*)(Cp + (rowc + j * 16) * 4);
+            }
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) {
+                f32x4 v = acc[i][j] + b4[j];
+                if (F32OUT) {
+                    if (EPI == VK_EPI_F32_ACC) v += cv[j];
+                    if (via_lds) *(f32x4 VK_LDS*)(uintptr_t)(lds_region + lrow * ROWB + (((j * 4 + gq) ^ (lrow & 7)) << 4)) = v;
+                    else *(f32x4*)(Cp + (rowc + j * 16) * 4) = v;
+                    continue;
+                }
+                float w[4] = {0.f, 0.f, 0.f, 0.f};
+                if (USE_R) { w[0] = bf2f(rv[j][0] & 0xFFFF); w[1] = bf2f(rv[j][0] >> 16); w[2] = bf2f(rv[j][1] & 0xFFFF); w[3] = bf2f(rv[j][1] >> 16); }
+                float o[4], o2[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    if (EPI == VK_EPI_BF16) o[r] = v[r];
+                    else if (EPI == VK_EPI_GELU) { gelu_both(v[r], o[r], o2[r]); }
+                    else if (EPI == VK_EPI_MULR) o[r] = v[r] * w[r];
+                    else if (EPI == VK_EPI_ADDR) o[r] = v[r] + w[r];
+                    else o[r] = fmaxf(v[r], 0.f);
+                }
+                const u32x2 pk = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                if (via_lds) {
+                    const uint32_t a = lrow * ROWB + (((j * 2 + (gq >> 1)) ^ (lrow & 7)) << 4) + ((gq & 1) << 3);
+                    *(u32x2 VK_LDS*)(uintptr_t)(lds_region + a) = pk;
+                    if (EPI == VK_EPI_GELU) *(u32x2 VK_LDS*)(uintptr_t)(img2 + a) = u32x2{pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3])};
+                } else {
+                    *(u32x2*)(Cp + (rowc + j * 16) * 2) = pk;
+                    if (EPI == VK_EPI_GELU) *(u32x2*)(C2p + (rowc + j * 16) * 2) = u32x2{pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3])};
+                }
+            }
+            if (via_lds && (i % TIH) == TIH - 1) {
+                // read the image(s) back row-major and store whole lines
+                const int rr0 = lane / CPR, ch = lane % CPR;
+                const int mrow0 = m_base + (i / TIH) * RPH;
+#pragma unroll
+                for (int q = 0; q < RPH / RPI; ++q) {
+                    const int row = q * RPI + rr0;
+                    const uint32_t a = row * ROWB + ((ch ^ (row & 7)) << 4);
+                    const size_t g = ((size_t)(mrow0 + row) * ldc + (size_t)n_base) * ES + (size_t)ch * 16;
+                    *(u32x4*)(Cp + g) = *(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a);
+                    if (EPI == VK_EPI_GELU) *(u32x4*)(C2p + g) = *(const u32x4 VK_LDS*)(uintptr_t)(img2 + a);
+                }
+            }
+        }
+        if (do_bias_grad && gq == 0) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const int m = m_base + i * 16 + lr;
+                P.bias_grad[m] = (EPI == VK_EPI_F32_ACC ? P.bias_grad[m] : 0.f) + accb[i][0];
+            }
+        }
+        return;
+    }
 
     float bv[TJ][4];
     {
