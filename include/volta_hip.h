@@ -319,7 +319,13 @@ enum {
     VK_OP_EMBED_FWD, VK_OP_EMBED_BWD, VK_OP_XENT_FWD,
     VK_OP_XENT_BWD,      /* a = vk_xent_args, b = dlogits, i0 = ldd, c = gscale */
     VK_OP_KL_FWD, VK_OP_KL_BWD,
-    VK_OP_GENERIC        /* a = vk_generic_args */
+    VK_OP_GENERIC,       /* a = vk_generic_args */
+    /* Side-stream control.  Weight gradients are off the critical path of the backward pass (the reference computes
+       them inside autograd's serial order, volta/encoders.py backward of every nn.Linear): the ops between SIDE_BEGIN
+       and SIDE_END run on the library's side stream, which first waits for everything issued so far on the caller's
+       stream; SIDE_END records event i0 (0..15) there, WAIT_SIDE makes the caller's stream wait for event i0 (no-op
+       if never recorded), JOIN makes it wait for everything issued on the side stream. */
+    VK_OP_SIDE_BEGIN, VK_OP_SIDE_END, VK_OP_WAIT_SIDE, VK_OP_JOIN
 };
 enum {
     VK_FN_CAST = 1, VK_FN_MEMSET, VK_FN_LOC_FWD, VK_FN_LOC_BWD, VK_FN_ADD_DROPOUT, VK_FN_COLSUM, VK_FN_SELECT,
@@ -340,8 +346,13 @@ typedef struct vk_op {
     const void* c;
 } vk_op;
 int vk_run_ops(const vk_op* ops, int n, vk_stream_t s);
-/* Same, bracketing each op with HIP events on `s`; synchronises `s` and adds elapsed ms per op to ms[0..n). */
+/* Same, bracketing each op with HIP events on `s`; synchronises `s` and adds elapsed ms per op to ms[0..n).
+   Side-stream blocks run inline on `s` here, so that every op's duration is attributed to it. */
 int vk_run_ops_timed(const vk_op* ops, int n, vk_stream_t s, float* ms);
+/* Make `s` wait for everything issued so far on the side stream (what VK_OP_JOIN does). */
+int vk_side_join(vk_stream_t s);
+/* 0: run side-stream blocks inline on the caller's stream (serial schedule); 1 (default): concurrently. */
+void vk_side_enable(int on);
 
 #ifdef __cplusplus
 }

@@ -94,7 +94,7 @@ class Op(C.Structure):
 
 
 (OP_GEMM, OP_LN_FWD, OP_LN_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_EMBED_FWD, OP_EMBED_BWD, OP_XENT_FWD, OP_XENT_BWD,
- OP_KL_FWD, OP_KL_BWD, OP_GENERIC) = range(1, 13)
+ OP_KL_FWD, OP_KL_BWD, OP_GENERIC, OP_SIDE_BEGIN, OP_SIDE_END, OP_WAIT_SIDE, OP_JOIN) = range(1, 17)
 (FN_CAST, FN_MEMSET, FN_LOC_FWD, FN_LOC_BWD, FN_ADD_DROPOUT, FN_COLSUM, FN_SELECT, FN_GATHER, FN_SCATTER_ADD,
  FN_LOSS_FINAL, FN_POOL_FWD, FN_POOL_BWD, FN_MASK_PREP, FN_MUL, FN_VLBERT_PREP, FN_VLBERT_MASKGRAD, FN_ROWGROUP_SUM,
  FN_RELU_BWD, FN_COPY, FN_SUM_SLABS, FN_SUM_SLABS_BF16) = range(1, 22)
@@ -165,6 +165,8 @@ _sig("vk_sum_slabs_bf16", C.c_int, c_p, c_p, C.c_int64, C.c_int, C.c_int64, c_p,
 _sig("vk_memset_async", C.c_int, c_p, C.c_int, C.c_int64, c_p)
 _sig("vk_run_ops", C.c_int, C.POINTER(Op), C.c_int, c_p)
 _sig("vk_run_ops_timed", C.c_int, C.POINTER(Op), C.c_int, c_p, C.POINTER(C.c_float))
+_sig("vk_side_join", C.c_int, c_p)
+_sig("vk_side_enable", None, C.c_int)
 
 EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_cast_f32_bf16", "vk_gemm_grouped",
            "vk_ln_fwd", "vk_ln_bwd_partial_rows", "vk_ln_bwd", "vk_gated_attn_fwd", "vk_gated_attn_bwd",
@@ -173,7 +175,7 @@ EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_c
            "vk_relu_bwd_bf16", "vk_copy_async", "vk_select_rows", "vk_gather_rows", "vk_scatter_rows_add", "vk_xent_fwd",
            "vk_xent_bwd", "vk_kl_fwd", "vk_kl_bwd", "vk_loss_finalize", "vk_pool_mul_fwd", "vk_pool_mul_bwd",
            "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_adamw_step",
-           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_run_ops", "vk_run_ops_timed"]
+           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_enable"]
 
 
 def check(rc):

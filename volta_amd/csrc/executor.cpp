@@ -9,11 +9,74 @@
 
 static int run_one(const vk_op& o, int i, vk_stream_t s);
 
+// ---- side stream: one per process (one process drives one GPU), created on first use
+namespace {
+constexpr int N_SIDE_EVENTS = 16;
+struct Side {
+    hipStream_t stream = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    hipEvent_t done[N_SIDE_EVENTS] = {};
+    bool recorded[N_SIDE_EVENTS] = {};
+    bool ok = false;
+};
+Side g_side;
+int g_side_enabled = 1;
+
+int side_init() {
+    if (g_side.ok) return 0;
+    if (hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking) != hipSuccess) return vk::set_error("side stream: hipStreamCreate failed");
+    if (hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming) != hipSuccess)
+        return vk::set_error("side stream: hipEventCreate failed");
+    for (int i = 0; i < N_SIDE_EVENTS; ++i)
+        if (hipEventCreateWithFlags(&g_side.done[i], hipEventDisableTiming) != hipSuccess) return vk::set_error("side stream: hipEventCreate failed");
+    g_side.ok = true;
+    return 0;
+}
+}  // namespace
+
+extern "C" void vk_side_enable(int on) { g_side_enabled = on; }
+
+extern "C" int vk_side_join(vk_stream_t s) {
+    if (!g_side.ok) return 0;           // nothing was ever issued on the side stream
+    if (hipEventRecord(g_side.join, g_side.stream) != hipSuccess) return vk::set_error("vk_side_join: hipEventRecord failed");
+    if (hipStreamWaitEvent((hipStream_t)s, g_side.join, 0) != hipSuccess) return vk::set_error("vk_side_join: hipStreamWaitEvent failed");
+    return 0;
+}
+
 extern "C" int vk_run_ops(const vk_op* ops, int n, vk_stream_t s) {
+    vk_stream_t cur = s;
     for (int i = 0; i < n; ++i) {
-        int rc = run_one(ops[i], i, s);
+        const vk_op& o = ops[i];
+        if (o.kind >= VK_OP_SIDE_BEGIN && o.kind <= VK_OP_JOIN) {
+            if (!g_side_enabled) continue;
+            if (side_init() != 0) return -1;
+            hipError_t e = hipSuccess;
+            switch (o.kind) {
+                case VK_OP_SIDE_BEGIN:
+                    e = hipEventRecord(g_side.fork, (hipStream_t)s);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(g_side.stream, g_side.fork, 0);
+                    cur = (vk_stream_t)g_side.stream;
+                    break;
+                case VK_OP_SIDE_END:
+                    if (o.i0 < 0 || o.i0 >= N_SIDE_EVENTS) return vk::set_error("vk_run_ops: side event %d out of range", o.i0);
+                    e = hipEventRecord(g_side.done[o.i0], g_side.stream);
+                    g_side.recorded[o.i0] = true;
+                    cur = s;
+                    break;
+                case VK_OP_WAIT_SIDE:
+                    if (o.i0 < 0 || o.i0 >= N_SIDE_EVENTS) return vk::set_error("vk_run_ops: side event %d out of range", o.i0);
+                    if (g_side.recorded[o.i0]) e = hipStreamWaitEvent((hipStream_t)s, g_side.done[o.i0], 0);
+                    break;
+                default:
+                    if (vk_side_join(s) != 0) return -1;
+            }
+            if (e != hipSuccess) return vk::set_error("vk_run_ops: side-stream control op %d failed at index %d: %s", o.kind, i, hipGetErrorString(e));
+            continue;
+        }
+        int rc = run_one(o, i, cur);
         if (rc != 0) return rc;
     }
+    if (cur != s) return vk::set_error("vk_run_ops: op list ends inside a side-stream block");
     return 0;
 }
 
@@ -29,8 +92,10 @@ extern "C" int vk_run_ops_timed(const vk_op* ops, int n, vk_stream_t s, float* m
     hipStream_t st = (hipStream_t)s;
     (void)hipEventRecord(ev[0], st);
     for (int i = 0; i < n; ++i) {
-        int rc = run_one(ops[i], i, s);
-        if (rc != 0) return rc;
+        if (!(ops[i].kind >= VK_OP_SIDE_BEGIN && ops[i].kind <= VK_OP_JOIN)) {     // control ops: nothing to launch, block runs inline
+            int rc = run_one(ops[i], i, s);
+            if (rc != 0) return rc;
+        }
         (void)hipEventRecord(ev[i + 1], st);
     }
     if (hipStreamSynchronize(st) != hipSuccess) return vk::set_error("vk_run_ops_timed: stream sync failed");

@@ -138,6 +138,10 @@ class Plan:
             else:
                 check(L.lib.vk_run_ops(base, end - start, L.stream_ptr()))
 
+    def join_side(self):
+        """Make the current stream wait for the side-stream work (weight gradients) issued so far."""
+        check(L.lib.vk_side_join(L.stream_ptr()))
+
     def enable_timing(self, on=True):
         """Per-op HIP-event timing (synchronises the stream on every run; profiling passes only)."""
         self.timing = (C.c_float * max(1, len(self.ops)))() if on else None
@@ -295,8 +299,16 @@ class StepEngine:
         else:
             raise NotImplementedError("image_embeddings=%r" % kind)
         self.taps["emb_t"], self.taps["emb_v"] = self.x[0], self.x[1]
-        for n, typ in sublayer_schedule(cfg):
-            bwd_stages.append(self._attn_sublayer(n) if typ == "attn" else self._ffn_sublayer(n))
+        # Weight gradients run on the executor's side stream (VK_OP_SIDE_*): sub-layer number k (forward order) keeps
+        # its backward temporaries in buffer set k % 2 and records side event k % 8 after its wgrad; its backward
+        # first waits for the event of sub-layer k + 2, the previous user of that buffer set.
+        self.n_sub = len(list(sublayer_schedule(cfg)))
+        for k, (n, typ) in enumerate(sublayer_schedule(cfg)):
+            self.sub_k = k
+            ops = self._attn_sublayer(n) if typ == "attn" else self._ffn_sublayer(n)
+            if k + 2 < self.n_sub:
+                ops.insert(0, (L.OP_WAIT_SIDE, (k + 2) % 8, 0, 0, None, None, None))
+            bwd_stages.append(ops)
             self.taps["t%d" % n], self.taps["v%d" % n] = self.x[0], self.x[1]
         head_bwd = self._heads()
         # backward list: zero-fills, heads, then stages in reverse; bwd_marks[s] = op index at which backward
@@ -306,6 +318,7 @@ class StepEngine:
         for ops in reversed(bwd_stages):
             self.bwd.ops += ops
             self.bwd_marks.append(len(self.bwd.ops))
+        self.bwd.ops.append((L.OP_JOIN, 0, 0, 0, None, None, None))
         prefixes = [["bert.t_pooler.", "bert.v_pooler.", "cls."]] + [pf for pf in reversed(self.stage_prefix)]
         self.param_ready_stage = {}
         for name in self.arena.params:
@@ -691,12 +704,13 @@ class StepEngine:
         for i, m in enumerate(ms):
             dxi[m], dxn[m] = self._dx_step(m)
             acc = 1 if (shared and i > 0) else 0
-            dz[m] = self.tmp("dz%d" % m, (self.st[m].M, H))
-            dd[m] = self.tmp("dd%d" % m, (self.st[m].M, H)) if self.train else dz[m]
+            par = self.sub_k % 2
+            dz[m] = self.tmp("dz%d_%d" % (m, par), (self.st[m].M, H))
+            dd[m] = self.tmp("dd%d_%d" % (m, par), (self.st[m].M, H)) if self.train else dz[m]
             b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dxi[m], d[m], mean[m], rstd[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", dz[m],
                                                               dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc), None, None))
             dctx[m] = self.tmp("dctx%d" % m, (self.st[m].M, H))
-            dqkv[m] = self.tmp("dqkv%d" % m, (self.st[m].M, 3 * H))
+            dqkv[m] = self.tmp("dqkv%d_%d" % (m, par), (self.st[m].M, 3 * H))
         self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dd[m], self.W(names[m]["o"] + ".weight"), dctx[m], self.st[m].M, H, H, H, H, H) for m in ms])
         ab = L.AttnBwdArgs()
         for m in ms:
@@ -739,11 +753,12 @@ class StepEngine:
         for i, m in enumerate(ms):
             dxi[m], dxn[m] = self._dx_step(m)
             acc = 1 if (shared and i > 0) else 0
-            dz[m] = self.tmp("dz%d" % m, (self.st[m].M, H))
-            dd[m] = self.tmp("dd%d" % m, (self.st[m].M, H)) if self.train else dz[m]
+            par = self.sub_k % 2
+            dz[m] = self.tmp("dz%d_%d" % (m, par), (self.st[m].M, H))
+            dd[m] = self.tmp("dd%d_%d" % (m, par), (self.st[m].M, H)) if self.train else dz[m]
             b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dxi[m], d[m], mean[m], rstd[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", dz[m],
                                                               dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc), None, None))
-            du[m] = self.tmp("du%d" % m, (self.st[m].M, I))
+            du[m] = self.tmp("du%d_%d" % (m, par), (self.st[m].M, I))
         self.gemm(b, L.NN, L.EPI_MULR, [self.prob(dd[m], self.W(names[m]["down"] + ".weight"), du[m], self.st[m].M, I, H, H, I, I, R=gp[m], ldr=I) for m in ms])
         self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(du[m], self.W(names[m]["up"] + ".weight"), dxn[m], self.st[m].M, H, I, I, H, H, R=dz[m], ldr=H) for m in ms])
         self._wgrad(b, ms, shared, [lambda m: (dd[m], h[m], self.G(names[m]["down"] + ".weight"), self.G(names[m]["down"] + ".bias"), H, I, H, I),
@@ -788,9 +803,11 @@ class StepEngine:
             reduces.append((gW, slab, stride, len(chunks), Mo * No))
             reduces.append((gB, slab[Mo * No:], stride, len(chunks), Mo))
         assert len(probs) <= 32, "too many wgrad problems in one group"
+        b.append((L.OP_SIDE_BEGIN, 0, 0, 0, None, None, None))
         self.gemm(b, L.TN, L.EPI_F32, probs)
         for dst, src, stride, ns, n in reduces:
             b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SUM_SLABS, p=(dst, src), n=(stride, ns, n)), None, None))
+        b.append((L.OP_SIDE_END, self.sub_k % 8, 0, 0, None, None, None))
         self._slab_cursor = 0
 
     def _slab(self, n):

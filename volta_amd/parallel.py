@@ -107,6 +107,7 @@ class DistributedDataParallel(nn.Module):
         start = 0
         for end, ranges in self._plan(eng):
             eng.bwd.run(start, end)
+            eng.bwd.join_side()          # the bucket's weight gradients were computed on the executor's side stream
             self.reducer.reduce(ranges)
             start = end
         eng.bwd.run(start, len(eng.bwd.ops))
