@@ -165,6 +165,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         losses = step()
+    t_issue = time.perf_counter() - t0       # host time to ISSUE the steps (the launches are asynchronous)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -180,6 +181,7 @@ def main():
            "config": {"workload": "%s pretrain step (fwd+bwd+clip+AdamW%s), per-GPU batch %d, T=%d, %d regions (+1 global), objective 1, dropout on"
                       % (a.config, "+allreduce" if world > 1 else "", a.batch, a.seq_len, a.regions),
                       "global_batch": a.batch * world, "seq_len": a.seq_len, "regions": a.regions, "parallelism": "dp%d" % world},
+           "host_issue_ms_per_step": t_issue * 1e3 / a.steps,
            "losses_last_step": [float(x) for x in losses]}
     if rank == 0:
         print("[bench] timed region done: %.3f ms/step, %.1f pairs/s" % (ms, pairs_s), file=sys.stderr, flush=True)

@@ -88,6 +88,17 @@ class ParamArena:
             n *= d
         return buf[o:o + n].view(self.shape[name])
 
+    def param_list(self):
+        if getattr(self, "_plist", None) is None or len(self._plist) != len(self.params):
+            self._plist = list(self.params.items())
+        return self._plist
+
+    def grad_views(self):
+        """One view of the gradient arena per parameter, created once (the hot loop only re-attaches them)."""
+        if getattr(self, "_gviews", None) is None or len(self._gviews) != len(self.params):
+            self._gviews = [self.view(n, "grad") for n in self.params]
+        return self._gviews
+
     def span(self, names, which, shape):
         """Contiguous view over consecutive tensors of one slot (the fused Q|K|V block)."""
         buf = getattr(self, which)

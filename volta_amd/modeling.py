@@ -223,6 +223,8 @@ class BertForVLPreTraining(PreTrainedModel):
         self.__dict__["_seed_base"] = int(seed)
         self.__dict__["_step"] = 0
 
+    _vk_is_model = True      # lets clip_grad_norm_(model.parameters()) recognise the whole arena without walking it
+
     def materialize(self, device=None):
         """Build (or rebuild) the flat parameter arenas on `device`; parameters become views of them."""
         from .engine import ParamArena
@@ -296,13 +298,14 @@ class BertForVLPreTraining(PreTrainedModel):
     def _engine_backward(self, g_lm, g_img, g_nsp):
         eng, tensors = self._last
         arena = eng.arena
-        params = list(arena.params.items())
-        have = [p.grad is not None for _, p in params]
-        accumulate = all(have)
-        if any(have) and not accumulate:
+        params = arena.param_list()                   # cached [(name, parameter)]
+        gviews = arena.grad_views()                   # cached views of the gradient arena, one per parameter
+        n_have = sum(p.grad is not None for _, p in params)
+        accumulate = n_have == len(params)
+        if n_have and not accumulate:
             raise RuntimeError("volta_amd: some parameters carry a .grad and some do not; zero_grad() all of them")
         if accumulate:
-            if not all(p.grad.data_ptr() == arena.view(n, "grad").data_ptr() for n, p in params):
+            if not all(p.grad is g or p.grad.data_ptr() == g.data_ptr() for (_, p), g in zip(params, gviews)):
                 raise RuntimeError("volta_amd: .grad tensors were replaced by foreign tensors; call zero_grad(set_to_none=True)")
             old = arena.grad.clone()
         eng.gout.copy_(torch.cat([g_lm.reshape(1), g_img.reshape(1), g_nsp.reshape(1)]).to(eng.gout))
@@ -315,8 +318,8 @@ class BertForVLPreTraining(PreTrainedModel):
             from . import _lib as L
             L.check(L.lib.vk_axpy_f32(L.ptr(arena.grad), L.ptr(old), 1.0, arena.total, L.stream_ptr()))
         else:
-            for n, p in params:
-                p.grad = arena.view(n, "grad")
+            for (_, p), g in zip(params, gviews):
+                p.grad = g
 
     # ------------------------------------------------------------------ public API
     def forward(self, input_ids, image_feat, image_loc, token_type_ids=None, attention_mask=None,

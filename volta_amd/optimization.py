@@ -12,6 +12,8 @@ import ctypes as C
 import math
 
 import torch
+import inspect
+
 from torch.optim import Optimizer
 from torch.optim.lr_scheduler import LambdaLR
 
@@ -130,9 +132,18 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, defer_to_optimizer=Fals
     coefficient is handed to the next AdamW.step(), which folds it into its single pass over the gradients."""
     if float(norm_type) != 2.0:
         raise NotImplementedError("only the L2 norm is supported")
-    params = [parameters] if isinstance(parameters, torch.Tensor) else list(parameters)
-    model, arena = _arena_of(params)
-    if any(p.grad is None or p.grad.data_ptr() != arena.view(n, "grad").data_ptr() for n, p in arena.params.items()):
+    model = None
+    if inspect.isgenerator(parameters) and parameters.gi_code is torch.nn.Module.parameters.__code__ and parameters.gi_frame is not None:
+        # `model.parameters()` of a volta_amd model, not started yet: the whole arena, no need to walk 600 tensors
+        owner = parameters.gi_frame.f_locals.get("self")
+        if getattr(owner, "_vk_is_model", False) and owner.__dict__.get("_arena") is not None:
+            model, arena = owner, owner.materialize()
+    if model is None:
+        params = [parameters] if isinstance(parameters, torch.Tensor) else list(parameters)
+        model, arena = _arena_of(params)
+        if len(params) != len(arena.params):
+            raise RuntimeError("clip_grad_norm_: pass every parameter of the model (the norm is taken over the whole gradient arena)")
+    if not all(p.grad is g or (p.grad is not None and p.grad.data_ptr() == g.data_ptr()) for (_, p), g in zip(arena.param_list(), arena.grad_views())):
         raise RuntimeError("clip_grad_norm_: gradients are not attached to the engine's arena (run backward first)")
     if not hasattr(arena, "norm_ws"):
         arena.norm_ws = torch.empty(L.lib.vk_grad_norm_workspace_floats(), device=arena.device)
