@@ -128,12 +128,16 @@ typedef struct vk_ln_bwd_args {
     int32_t split_row;
     int32_t post;
     float out_scale;
-    int32_t accumulate;    /* != 0: dgamma / dbeta += (shared sub-layers: one LayerNorm, two modalities) */
+    int32_t accumulate;    /* bit 0: dgamma / dbeta += (shared sub-layers: one LayerNorm, two modalities);
+                              bit 1: leave the column reduction of `partial` to a later vk_ln_bwd_finalize (same args) */
     vk_dropout drop;
     vk_drop_rows seg[2];
 } vk_ln_bwd_args;
 int vk_ln_bwd_partial_rows(int M);
 int vk_ln_bwd(const vk_ln_bwd_args* a, vk_stream_t s);
+/* dgamma / dbeta from the per-workgroup partial records of a vk_ln_bwd issued with accumulate bit 1 set: off the
+   critical path of the backward pass (the parameters' gradients are only needed by the optimizer / all-reduce). */
+int vk_ln_bwd_finalize(const vk_ln_bwd_args* a, vk_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * Gated bimodal attention.  Replaces the body of BertGatedSelfAttention.forward after the Q/K/V
@@ -325,7 +329,8 @@ enum {
        and SIDE_END run on the library's side stream, which first waits for everything issued so far on the caller's
        stream; SIDE_END records event i0 (0..15) there, WAIT_SIDE makes the caller's stream wait for event i0 (no-op
        if never recorded), JOIN makes it wait for everything issued on the side stream. */
-    VK_OP_SIDE_BEGIN, VK_OP_SIDE_END, VK_OP_WAIT_SIDE, VK_OP_JOIN
+    VK_OP_SIDE_BEGIN, VK_OP_SIDE_END, VK_OP_WAIT_SIDE, VK_OP_JOIN,
+    VK_OP_LN_FINALIZE    /* a = vk_ln_bwd_args of the deferred vk_ln_bwd */
 };
 enum {
     VK_FN_CAST = 1, VK_FN_MEMSET, VK_FN_LOC_FWD, VK_FN_LOC_BWD, VK_FN_ADD_DROPOUT, VK_FN_COLSUM, VK_FN_SELECT,

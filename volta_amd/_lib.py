@@ -94,7 +94,7 @@ class Op(C.Structure):
 
 
 (OP_GEMM, OP_LN_FWD, OP_LN_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_EMBED_FWD, OP_EMBED_BWD, OP_XENT_FWD, OP_XENT_BWD,
- OP_KL_FWD, OP_KL_BWD, OP_GENERIC, OP_SIDE_BEGIN, OP_SIDE_END, OP_WAIT_SIDE, OP_JOIN) = range(1, 17)
+ OP_KL_FWD, OP_KL_BWD, OP_GENERIC, OP_SIDE_BEGIN, OP_SIDE_END, OP_WAIT_SIDE, OP_JOIN, OP_LN_FINALIZE) = range(1, 18)
 (FN_CAST, FN_MEMSET, FN_LOC_FWD, FN_LOC_BWD, FN_ADD_DROPOUT, FN_COLSUM, FN_SELECT, FN_GATHER, FN_SCATTER_ADD,
  FN_LOSS_FINAL, FN_POOL_FWD, FN_POOL_BWD, FN_MASK_PREP, FN_MUL, FN_VLBERT_PREP, FN_VLBERT_MASKGRAD, FN_ROWGROUP_SUM,
  FN_RELU_BWD, FN_COPY, FN_SUM_SLABS, FN_SUM_SLABS_BF16) = range(1, 22)
@@ -165,11 +165,12 @@ _sig("vk_sum_slabs_bf16", C.c_int, c_p, c_p, C.c_int64, C.c_int, C.c_int64, c_p,
 _sig("vk_memset_async", C.c_int, c_p, C.c_int, C.c_int64, c_p)
 _sig("vk_run_ops", C.c_int, C.POINTER(Op), C.c_int, c_p)
 _sig("vk_run_ops_timed", C.c_int, C.POINTER(Op), C.c_int, c_p, C.POINTER(C.c_float))
+_sig("vk_ln_bwd_finalize", C.c_int, C.POINTER(LnBwdArgs), c_p)
 _sig("vk_side_join", C.c_int, c_p)
 _sig("vk_side_enable", None, C.c_int)
 
 EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_cast_f32_bf16", "vk_gemm_grouped",
-           "vk_ln_fwd", "vk_ln_bwd_partial_rows", "vk_ln_bwd", "vk_gated_attn_fwd", "vk_gated_attn_bwd",
+           "vk_ln_fwd", "vk_ln_bwd_partial_rows", "vk_ln_bwd", "vk_ln_bwd_finalize", "vk_gated_attn_fwd", "vk_gated_attn_bwd",
            "vk_embed_sum_fwd", "vk_embed_sum_bwd", "vk_rows32", "vk_loc_linear_fwd", "vk_loc_linear_bwd",
            "vk_add_dropout", "vk_colsum_bf16", "vk_vlbert_prep_fwd", "vk_vlbert_maskgrad", "vk_rowgroup_sum_bf16",
            "vk_relu_bwd_bf16", "vk_copy_async", "vk_select_rows", "vk_gather_rows", "vk_scatter_rows_add", "vk_xent_fwd",

@@ -272,7 +272,17 @@ extern "C" int vk_ln_bwd(const vk_ln_bwd_args* a, vk_stream_t stream) {
         case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, *a); break;
         default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, *a); break;
     }
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * a->H + 63) / 64), dim3(1024), 0, s, a->partial, nblk, a->H,
-                       a->dgamma, a->dbeta, a->accumulate);
+    if (!(a->accumulate & 2))
+        hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * a->H + 63) / 64), dim3(1024), 0, s, a->partial, nblk, a->H,
+                           a->dgamma, a->dbeta, a->accumulate & 1);
     return check_launch("vk_ln_bwd");
+}
+
+extern "C" int vk_ln_bwd_finalize(const vk_ln_bwd_args* a, vk_stream_t stream) {
+    using namespace vk;
+    if (a->M <= 0) return 0;
+    const int nblk = vk_ln_bwd_partial_rows(a->M);
+    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * a->H + 63) / 64), dim3(1024), 0, (hipStream_t)stream, a->partial, nblk, a->H,
+                       a->dgamma, a->dbeta, a->accumulate & 1);
+    return check_launch("vk_ln_bwd_finalize");
 }

@@ -15,6 +15,7 @@ vv, vt probabilities, text output, vision output; pooled) -- the contract the ma
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -269,12 +270,22 @@ class StepEngine:
                      _addr(rstd), _addr(dyn), M, self.H, M, post, out_scale, drop, _mk_segs(drop, segs))
         return self.k(a)
 
-    def ln_bwd_args(self, dy, z, mean, rstd, gname, bname, dz, dd, M, drop, post=0, out_scale=1.0, dyn=None, segs=None, accumulate=0):
-        partial = self.tmp("ln_partial", (L.lib.vk_ln_bwd_partial_rows(max(self.st[0].M, self.st[1].M)) * 2 * self.H,), torch.float32)
+    def ln_bwd_args(self, dy, z, mean, rstd, gname, bname, dz, dd, M, drop, post=0, out_scale=1.0, dyn=None, segs=None, accumulate=0, defer=False):
+        """`defer`: the dgamma / dbeta column reduction is left to an OP_LN_FINALIZE that the next _wgrad() places in its
+        side-stream block; the partial records then need a buffer of their own."""
+        if defer:
+            self._n_ln_partial = getattr(self, "_n_ln_partial", 0) + 1
+            partial = self.buf("ln_partial_%d" % self._n_ln_partial, (L.lib.vk_ln_bwd_partial_rows(M) * 2 * self.H,), torch.float32)
+            accumulate |= 2
+        else:
+            partial = self.tmp("ln_partial", (L.lib.vk_ln_bwd_partial_rows(max(self.st[0].M, self.st[1].M)) * 2 * self.H,), torch.float32)
         a = L.LnBwdArgs(_addr(dy), _addr(z), _addr(mean), _addr(rstd), _addr(self.Pm(gname)), _addr(dz), _addr(dd), _addr(partial),
                         _addr(self.G(gname)), _addr(self.G(bname)), _addr(dyn), M, self.H, M, post, out_scale, accumulate, drop,
                         _mk_segs(drop, segs))
-        return self.k(a)
+        a = self.k(a)
+        if defer:
+            self._deferred_ln = getattr(self, "_deferred_ln", []) + [a]
+        return a
 
     # ---------------------------------------------------------------- build
     def _build(self):
@@ -719,7 +730,7 @@ class StepEngine:
             dz[m] = self.tmp("dz%d_%d" % (m, par), (self.st[m].M, H))
             dd[m] = self.tmp("dd%d_%d" % (m, par), (self.st[m].M, H)) if self.train else dz[m]
             b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dxi[m], d[m], mean[m], rstd[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", dz[m],
-                                                              dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc), None, None))
+                                                              dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc, defer=True), None, None))
             dctx[m] = self.tmp("dctx%d" % m, (self.st[m].M, H))
             dqkv[m] = self.tmp("dqkv%d_%d" % (m, par), (self.st[m].M, 3 * H))
         self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dd[m], self.W(names[m]["o"] + ".weight"), dctx[m], self.st[m].M, H, H, H, H, H) for m in ms])
@@ -768,7 +779,7 @@ class StepEngine:
             dz[m] = self.tmp("dz%d_%d" % (m, par), (self.st[m].M, H))
             dd[m] = self.tmp("dd%d_%d" % (m, par), (self.st[m].M, H)) if self.train else dz[m]
             b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dxi[m], d[m], mean[m], rstd[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", dz[m],
-                                                              dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc), None, None))
+                                                              dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc, defer=True), None, None))
             du[m] = self.tmp("du%d_%d" % (m, par), (self.st[m].M, I))
         self.gemm(b, L.NN, L.EPI_MULR, [self.prob(dd[m], self.W(names[m]["down"] + ".weight"), du[m], self.st[m].M, I, H, H, I, I, R=gp[m], ldr=I) for m in ms])
         self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(du[m], self.W(names[m]["up"] + ".weight"), dxn[m], self.st[m].M, H, I, I, H, H, R=dz[m], ldr=H) for m in ms])
@@ -795,7 +806,7 @@ class StepEngine:
         for gW, gB, Mo, No, srcs in jobs:
             chunks = []
             for dY, X, rows, lda, ldb in srcs:
-                ns = max(1, int(round(rows / 5120.0)))
+                ns = max(1, int(round(rows / float(os.environ.get('VK_WGRAD_CHUNK', '5120')))))
                 step = -(-rows // ns)
                 step = -(-step // 64) * 64
                 r0 = 0
@@ -818,6 +829,9 @@ class StepEngine:
         self.gemm(b, L.TN, L.EPI_F32, probs)
         for dst, src, stride, ns, n in reduces:
             b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SUM_SLABS, p=(dst, src), n=(stride, ns, n)), None, None))
+        for a in getattr(self, "_deferred_ln", []):          # LayerNorm parameter gradients of this sub-layer
+            b.append((L.OP_LN_FINALIZE, 0, 0, 0, a, None, None))
+        self._deferred_ln = []
         b.append((L.OP_SIDE_END, self.sub_k % 8, 0, 0, None, None, None))
         self._slab_cursor = 0
 
