@@ -73,6 +73,27 @@ def ablate():
     L.lib.vk_gemm_set_tile(0)
 
 
+def peak():
+    """Sustained MFMA rate on register operands (no memory traffic): the ceiling of any GEMM main loop here."""
+    import ctypes
+    f = L.lib.vk_mfma_peak
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    seed = torch.randint(1, 2 ** 31 - 1, (64,), device="cuda", dtype=torch.int32)
+    out = torch.zeros(4, device="cuda")
+    for blocks in (256, 512):
+        for iters in (2000, 20000):
+            f(seed.data_ptr(), out.data_ptr(), 100, blocks, ops.stream_ptr())
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            f(seed.data_ptr(), out.data_ptr(), iters, blocks, ops.stream_ptr())
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1)
+            fl = blocks * 8 * iters * 16 * 16384.0
+            print("mfma peak: %d blocks x 8 waves, %d iters: %.3f ms  %.0f TF/s" % (blocks, iters, ms, fl / ms / 1e9), flush=True)
+
+
 def blas(name, layout, M, N, K, iters=20):
     """Vendor BLAS (torch.matmul -> hipBLASLt) on the same shape: a known-good yardstick for the headroom, never part of the product."""
     g = torch.Generator(device="cuda").manual_seed(0)
@@ -114,6 +135,9 @@ def vendor():
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "sweep":
         sweep()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "peak":
+        peak()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ablate":
         ablate()

@@ -56,3 +56,43 @@ extern "C" int vk_cast_f32_bf16(const float* src, void* dst, int64_t n, vk_strea
     hipLaunchKernelGGL(vk::cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)s, src, (uint16_t*)dst, (size_t)n);
     return vk::check_launch("vk_cast_f32_bf16");
 }
+
+// ---- measurement aid (tools/bench_gemm.py peak): sustained rate of v_mfma_f32_16x16x32_bf16 on register operands,
+// 8 waves per CU, 16 independent accumulators per wave -- the ceiling any GEMM main loop on this chip can approach.
+namespace vk {
+__global__ __launch_bounds__(512) void mfma_peak_kernel(const uint32_t* seed, float* out, int iters) {
+    typedef __attribute__((ext_vector_type(8))) short v8;
+    typedef __attribute__((ext_vector_type(4))) float v4;
+    v8 a[4], b[4];
+    const uint32_t s = seed[threadIdx.x & 63] + blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            a[i][k] = (short)(0x3C00 + ((s * (i * 8 + k + 1) * 2654435761u) >> 22));      // bf16 values of varying mantissa
+            b[i][k] = (short)(0xBC00 + ((s * (i * 8 + k + 77) * 40503u) >> 22));
+        }
+    v4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = v4{0.f, 0.f, 0.f, 0.f};
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+    if (t == 12345.678f) out[0] = t;
+}
+}  // namespace vk
+
+extern "C" int vk_mfma_peak(const uint32_t* seed64, float* out, int iters, int blocks, vk_stream_t stream) {
+    hipLaunchKernelGGL(vk::mfma_peak_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, seed64, out, iters);
+    return vk::check_launch("vk_mfma_peak");
+}
