@@ -260,16 +260,28 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
         return true;
     }();
     (void)env_once;
+    // Geometry (tuning hook values in brackets): 128 x 128 [128], 256 x 256 K-split [258], 256 x 192 K-split [259],
+    // 256 x 256 4-phase [256], legacy 16-wave 256 x 256 [257].  The heuristic takes 256-row tiles whenever they still
+    // yield >= g_min_tiles256 workgroups, and of the two widths the one with less work on the busiest CU:
+    // rounds(tiles / 256 CUs) x tile width.  N = 768 -> 4 column tiles of 192 instead of 3 of 256 (228 instead of
+    // 171 workgroups for the ViLBERT row counts: one round of smaller tiles), N = 2304 -> 12 instead of 9.
     int edge = g_tile_override;
-    if (edge == 0) edge = total_tiles(probs, nprob, epilogue, 256, 256) >= g_min_tiles256 ? 258 : 128;
-    if (edge == 256 || edge == 258) {
+    if (edge == 0) {
+        const int t256 = total_tiles(probs, nprob, epilogue, 256, 256), t192 = total_tiles(probs, nprob, epilogue, 256, 192);
+        if (t256 < g_min_tiles256) edge = 128;
+        else {
+            const double c256 = (double)((t256 + 255) / 256) * 256.0, c192 = (double)((t192 + 255) / 256) * 192.0;
+            edge = c192 < 0.97 * c256 ? 259 : 258;
+        }
+    }
+    if (edge == 256 || edge == 258 || edge == 259) {
         for (int i = 0; i < nprob; ++i) {
             const vk_gemm_problem& q = probs[i];
             const uint64_t ea = (uint64_t)(layout == VK_TN ? q.K : q.M) * q.lda * 2, eb = (uint64_t)(layout == VK_NT ? q.N : q.K) * q.ldb * 2;
-            if (ea >= 0x80000000ull || eb >= 0x80000000ull) { edge = 128; break; }     // the 8-phase kernel addresses operands below 2 GiB
+            if (ea >= 0x7FFFFFF0ull || eb >= 0x7FFFFFF0ull) { edge = 128; break; }     // the LDS-DMA kernels address operands below 2 GiB
         }
     }
-    const int bm = edge == 128 ? 128 : 256, bn = bm;
+    const int bm = edge == 128 ? 128 : 256, bn = edge == 259 ? 192 : bm;
     KGroup g;
     g.nprob = nprob;
     g.stagger = g_stagger | (g_debug << 8);
@@ -287,7 +299,7 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
     }
     if (total == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (edge == 256 || edge == 258) return launch_gemm256(layout, epilogue, g, total, s, edge == 258);
+    if (edge == 256 || edge == 258 || edge == 259) return launch_gemm256(layout, epilogue, g, total, s, edge == 258 ? 4 : edge == 259 ? 3 : 0);
     if (edge == 257) {
         if (layout == VK_NT) return launch_cfg<false, false, 4, 4, false>(epilogue, g, total, s);
         if (layout == VK_NN) return launch_cfg<false, true, 4, 4, false>(epilogue, g, total, s);

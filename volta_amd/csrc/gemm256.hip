@@ -235,17 +235,22 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const KGroup g) {
 // a 256-byte bank row once.  Transposed operand: [32 k][256], 512-byte rows, read with ds_read_b64_tr_b16.
 __device__ __forceinline__ int kswz(int r) { return (-(r >> 2)) & 3; }
 
+constexpr uint32_t MASKED = 0x7FFFFFF0u;     // per-lane offset of a piece outside the tile: stays out of range for every K-step
+
+// `ext` rows (K-contiguous operand) / columns (transposed operand) of the 256-wide strip image belong to the tile;
+// the pieces beyond are issued out of range (zero fill, no traffic) so that every wave issues the same DMA count.
 template <bool T>
-__device__ __forceinline__ void strip_offsets(uint32_t (&off)[2], int ld, int ext0, int tid) {
+__device__ __forceinline__ void strip_offsets(uint32_t (&off)[2], int ld, int ext0, int ext, int tid) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int lin = i * 512 + tid;
         if (!T) {
             const int r = lin >> 2, cp = lin & 3;
-            off[i] = ((uint32_t)(ext0 + r) * (uint32_t)ld + (uint32_t)((cp ^ kswz(r)) * 8)) * 2u;
+            off[i] = r < ext ? ((uint32_t)(ext0 + r) * (uint32_t)ld + (uint32_t)((cp ^ kswz(r)) * 8)) * 2u : MASKED;
         } else {
             const int kr = lin >> 5, cp = lin & 31;
-            off[i] = ((uint32_t)kr * (uint32_t)ld + (uint32_t)(ext0 + (cp ^ tswz(kr)) * 8)) * 2u;
+            const int c = cp ^ tswz(kr);
+            off[i] = c * 8 < ext ? ((uint32_t)kr * (uint32_t)ld + (uint32_t)(ext0 + c * 8)) * 2u : MASKED;
         }
     }
 }
@@ -255,10 +260,13 @@ __device__ __forceinline__ bf16x8 frag_strip(uint32_t strip, int r0, int lane) {
     return *(const bf16x8 VK_LDS*)(uintptr_t)(strip + r * 64 + (((lane >> 4) ^ kswz(r)) << 4));
 }
 
-template <bool AT, bool BT, int EPI>
+// TJ = 16-column tiles per wave along N: 4 -> 256 x 256 tile, 3 -> 256 x 192 (N = 768 / 2304 split into 4 / 12 column
+// tiles instead of 3 / 9: 171 -> 228 and 513 -> 684 workgroups for the ViLBERT shapes, i.e. fuller rounds of smaller tiles).
+template <bool AT, bool BT, int EPI, int TJ>
 __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
     constexpr bool BG = AT && BT;
     constexpr int RING = 5;
+    constexpr int BN = 64 * TJ, WN = 16 * TJ;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(VK_LDS char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
     const KProb& P = g.p[pi];
     const int t = bid - P.tile_start;
     const int tm = t / P.tiles_n, tn = t - tm * P.tiles_n;
-    const int m0 = tm * 256, n0 = tn * 256;
+    const int m0 = tm * 256, n0 = tn * BN;
 
     int M = P.M, K = P.K;
     if (P.dyn) {
@@ -288,8 +296,8 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(P.B, b_rows > 0 ? (uint32_t)(((uint32_t)(b_rows - 1) * P.ldb + b_cols) * 2u) : 0u);
 
     uint32_t offA[2], offB[2];
-    strip_offsets<AT>(offA, P.lda, m0, tid);
-    strip_offsets<BT>(offB, P.ldb, n0, tid);
+    strip_offsets<AT>(offA, P.lda, m0, 256, tid);
+    strip_offsets<BT>(offB, P.ldb, n0, BN, tid);
     const uint32_t kA = AT ? 64u * (uint32_t)P.lda : 64u, kB = BT ? 64u * (uint32_t)P.ldb : 64u;     // bytes per 32-deep K-step
     const int np = (K + 31) / 32;
     const int dbg = g.stagger >> 8;
@@ -303,11 +311,11 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
         stage_half(rsB, sa + HT, offB, live ? (uint32_t)p * kB : OOB, wave);
     };
 
-    f32x4 acc[8][4];
+    f32x4 acc[8][TJ];
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 accb[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -325,10 +333,10 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
     int rd = 0, wrs = 3;           // ring slots of the K-step read / staged in this phase
     for (int p = 0; p < np; ++p) {
         const uint32_t sa = lds0 + (uint32_t)rd * 2u * HT, sb = sa + HT;
-        bf16x8 a[8], b[4];
+        bf16x8 a[8], b[TJ];
         if (!(dbg & 4)) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) b[j] = BT ? frag_cols<512>(sb, wc * 64 + j * 16, 0, lane) : frag_strip(sb, wc * 64 + j * 16, lane);
+            for (int j = 0; j < TJ; ++j) b[j] = BT ? frag_cols<512>(sb, wc * WN + j * 16, 0, lane) : frag_strip(sb, wc * WN + j * 16, lane);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < 8; ++i) a[i] = AT ? frag_cols<512>(sa, wr * 128 + i * 16, 0, lane) : frag_strip(sa, wr * 128 + i * 16, lane);
@@ -342,7 +350,7 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
 #pragma unroll
             for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j)
+                for (int j = 0; j < TJ; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
             if (BG && do_bias_grad) {
 #pragma unroll
@@ -358,15 +366,15 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     VK_SYNC();
 
-    gemm_epilogue<AT, EPI, 8, 4>(P, acc, accb, do_bias_grad, m0 + wr * 128, n0 + wc * 64, M, lane, lds0 + (uint32_t)wave * 16384u);
+    gemm_epilogue<AT, EPI, 8, TJ>(P, acc, accb, do_bias_grad, m0 + wr * 128, n0 + wc * WN, M, lane, lds0 + (uint32_t)wave * 16384u);
 }
 
-template <bool AT, bool BT, bool KSPLIT>
+template <bool AT, bool BT, int KSPLIT>      // 0: 4-phase 256 x 256, 4 / 3: K-split kernel with 256 / 192 columns
 static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s) {
     constexpr int LDS = (KSPLIT ? 10 : 8) * HT;
 #define VK_CASE(E)                                                                                        \
     case E: {                                                                                             \
-        auto k = KSPLIT ? gemm256k_kernel<AT, BT, E> : gemm256_kernel<AT, BT, E>;                         \
+        auto k = KSPLIT == 3 ? gemm256k_kernel<AT, BT, E, 3> : KSPLIT == 4 ? gemm256k_kernel<AT, BT, E, 4> : gemm256_kernel<AT, BT, E>; \
         static bool once = false;                                                                         \
         if (!once) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; } \
         hipLaunchKernelGGL(k, dim3(total), dim3(512), LDS, s, g);                                         \
@@ -380,15 +388,20 @@ static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s) {
     return check_launch("vk_gemm_grouped");
 }
 
-int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, bool ksplit) {
-    if (ksplit) {
-        if (layout == VK_NT) return launch_layout<false, false, true>(epilogue, g, total, s);
-        if (layout == VK_NN) return launch_layout<false, true, true>(epilogue, g, total, s);
-        if (layout == VK_TN) return launch_layout<true, true, true>(epilogue, g, total, s);
+int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant) {
+    if (variant == 3) {
+        if (layout == VK_NT) return launch_layout<false, false, 3>(epilogue, g, total, s);
+        if (layout == VK_NN) return launch_layout<false, true, 3>(epilogue, g, total, s);
+        if (layout == VK_TN) return launch_layout<true, true, 3>(epilogue, g, total, s);
     }
-    if (layout == VK_NT) return launch_layout<false, false, false>(epilogue, g, total, s);
-    if (layout == VK_NN) return launch_layout<false, true, false>(epilogue, g, total, s);
-    if (layout == VK_TN) return launch_layout<true, true, false>(epilogue, g, total, s);
+    if (variant == 4) {
+        if (layout == VK_NT) return launch_layout<false, false, 4>(epilogue, g, total, s);
+        if (layout == VK_NN) return launch_layout<false, true, 4>(epilogue, g, total, s);
+        if (layout == VK_TN) return launch_layout<true, true, 4>(epilogue, g, total, s);
+    }
+    if (layout == VK_NT) return launch_layout<false, false, 0>(epilogue, g, total, s);
+    if (layout == VK_NN) return launch_layout<false, true, 0>(epilogue, g, total, s);
+    if (layout == VK_TN) return launch_layout<true, true, 0>(epilogue, g, total, s);
     return set_error("vk_gemm_grouped: unknown layout %d", layout);
 }
 

@@ -82,14 +82,17 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
         const int ldc = P.ldc, ldr = P.ldr;
         constexpr int ES = F32OUT ? 4 : 2;                     // bytes per output element
         constexpr int ROWB = TJ * 16 * ES;                     // bytes per image row
+        constexpr bool POW2 = (TJ & (TJ - 1)) == 0;            // XOR swizzle needs 2^k chunks per row; otherwise rows are padded by 16 bytes
+        constexpr int PITCH = POW2 ? ROWB : ROWB + 16;
         constexpr int NIMG = (EPI == VK_EPI_GELU) ? 2 : 1;
-        constexpr int RPH0 = 16384 / (ROWB * NIMG);            // rows per pass through the 16 KiB region
-        constexpr int RPH = RPH0 < TI * 16 ? RPH0 : TI * 16;
-        constexpr int TIH = RPH / 16;                          // row tiles per pass
+        constexpr int RPH0 = 16384 / (PITCH * NIMG);           // rows per pass through the 16 KiB region
+        constexpr int TIH = RPH0 >= TI * 16 ? TI : (RPH0 >= TI * 8 ? TI / 2 : TI / 4);    // row tiles per pass (divides TI)
+        constexpr int RPH = TIH * 16;
         constexpr int CPR = ROWB / 16;                         // 16-byte chunks per row
         constexpr int RPI = 64 / CPR;                          // rows per store instruction
+        static_assert(TIH >= 1 && RPH * PITCH * NIMG <= 16384, "epilogue staging does not fit its 16 KiB region");
         const bool via_lds = lds_region != 0 && ((ldc * ES) & 15) == 0 && (((uintptr_t)Cp | (uintptr_t)C2p) & 15) == 0;
-        const uint32_t img2 = lds_region + RPH * ROWB;
+        const uint32_t img2 = lds_region + RPH * PITCH;
         f32x4 b4[TJ];
         {
             const bool has_bias = (EPI != VK_EPI_MULR) && (P.bias != nullptr);
@@ -120,7 +123,7 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
                 f32x4 v = acc[i][j] + b4[j];
                 if (F32OUT) {
                     if (EPI == VK_EPI_F32_ACC) v += cv[j];
-                    if (via_lds) *(f32x4 VK_LDS*)(uintptr_t)(lds_region + lrow * ROWB + (((j * 4 + gq) ^ (lrow & 7)) << 4)) = v;
+                    if (via_lds) *(f32x4 VK_LDS*)(uintptr_t)(lds_region + lrow * PITCH + (((j * 4 + gq) ^ (POW2 ? (lrow & 7) : 0)) << 4)) = v;
                     else *(f32x4*)(Cp + (rowc + j * 16) * 4) = v;
                     continue;
                 }
@@ -137,7 +140,7 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
                 }
                 const u32x2 pk = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
                 if (via_lds) {
-                    const uint32_t a = lrow * ROWB + (((j * 2 + (gq >> 1)) ^ (lrow & 7)) << 4) + ((gq & 1) << 3);
+                    const uint32_t a = lrow * PITCH + (((j * 2 + (gq >> 1)) ^ (POW2 ? (lrow & 7) : 0)) << 4) + ((gq & 1) << 3);
                     *(u32x2 VK_LDS*)(uintptr_t)(lds_region + a) = pk;
                     if (EPI == VK_EPI_GELU) *(u32x2 VK_LDS*)(uintptr_t)(img2 + a) = u32x2{pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3])};
                 } else {
@@ -150,9 +153,10 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
                 const int rr0 = lane / CPR, ch = lane % CPR;
                 const int mrow0 = m_base + (i / TIH) * RPH;
 #pragma unroll
-                for (int q = 0; q < RPH / RPI; ++q) {
+                for (int q = 0; q < (RPH + RPI - 1) / RPI; ++q) {
                     const int row = q * RPI + rr0;
-                    const uint32_t a = row * ROWB + ((ch ^ (row & 7)) << 4);
+                    if ((RPI * CPR < 64 && rr0 >= RPI) || ((RPH % RPI) && row >= RPH)) continue;
+                    const uint32_t a = row * PITCH + ((ch ^ (POW2 ? (row & 7) : 0)) << 4);
                     const size_t g = ((size_t)(mrow0 + row) * ldc + (size_t)n_base) * ES + (size_t)ch * 16;
                     *(u32x4*)(Cp + g) = *(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a);
                     if (EPI == VK_EPI_GELU) *(u32x4*)(C2p + g) = *(const u32x4 VK_LDS*)(uintptr_t)(img2 + a);
@@ -265,6 +269,6 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
 }
 
 // 256 x 256 tile, 8 waves, 8-phase LDS-DMA pipeline (gemm256.hip)
-int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, bool ksplit);
+int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant);   // 0: 4-phase, 4 / 3: K-split with 256 / 192 columns
 
 }  // namespace vk
