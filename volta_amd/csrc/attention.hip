@@ -39,13 +39,47 @@ __device__ __forceinline__ bf16x8 img_tr_frag(uint32_t img, int rbase, int d0, i
     return r;
 }
 
-// cooperative staging of rows [0, L) x 64 dims of one head into an image of RP rows (zero padded)
-__device__ __forceinline__ void stage_img(uint32_t img, const uint16_t* base, int ld, int L, int RP, int tid, int nthr) {
-    for (int idx = tid; idx < RP * 8; idx += nthr) {
-        const int row = idx >> 3, ch = idx & 7;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (row < L) v = *(const u32x4*)(base + (size_t)row * ld + ch * 8);
-        *(u32x4 VK_LDS*)(uintptr_t)(img + img_off(row, ch * 8)) = v;
+// Cooperative staging of rows [0, L) x 64 dims of one head into an image of RPAD rows (zero padded), split into a
+// LOAD half and a STORE half: a kernel first issues the global loads of ALL its images (K, V, Q, dO, O of both
+// modalities) and only then writes LDS, so the workgroup pays one memory latency instead of one per image
+// (staging image after image cost 8-12 dependent round trips, most of a backward workgroup's lifetime).
+// Needs >= 256 threads (pieces per thread are sized for 256).
+template <int RPAD> struct StagePieces { static constexpr int N = (RPAD * 8 + 255) / 256; };
+template <int RPAD>
+__device__ __forceinline__ void stage_load(u32x4 (&r)[StagePieces<RPAD>::N], const uint16_t* base, int ld, int L, int tid, int nthr) {
+#pragma unroll
+    for (int i = 0; i < StagePieces<RPAD>::N; ++i) {
+        const int idx = i * nthr + tid, row = idx >> 3, ch = idx & 7;
+        r[i] = u32x4{0u, 0u, 0u, 0u};
+        if (idx < RPAD * 8 && row < L) r[i] = *(const u32x4*)(base + (size_t)row * ld + ch * 8);
+    }
+}
+template <int RPAD>
+__device__ __forceinline__ void stage_store(uint32_t img, const u32x4 (&r)[StagePieces<RPAD>::N], int tid, int nthr) {
+#pragma unroll
+    for (int i = 0; i < StagePieces<RPAD>::N; ++i) {
+        const int idx = i * nthr + tid, row = idx >> 3, ch = idx & 7;
+        if (idx < RPAD * 8) *(u32x4 VK_LDS*)(uintptr_t)(img + img_off(row, ch * 8)) = r[i];
+    }
+}
+// delta[row] = sum_d dO[row][d] * O[row][d] from the staged registers (8 lanes per row), plus the lse copy
+template <int RPAD>
+__device__ __forceinline__ void delta_rows(const u32x4 (&rg)[StagePieces<RPAD>::N], const u32x4 (&ro)[StagePieces<RPAD>::N], float VK_LDS* del_s,
+                                           float VK_LDS* lse_s, const float* lse, int L, int tid, int nthr) {
+#pragma unroll
+    for (int i = 0; i < StagePieces<RPAD>::N; ++i) {
+        const int idx = i * nthr + tid, row = idx >> 3, ch = idx & 7;
+        float part = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            part += bf2f(rg[i][k] & 0xFFFF) * bf2f(ro[i][k] & 0xFFFF) + bf2f(rg[i][k] >> 16) * bf2f(ro[i][k] >> 16);
+        part += __shfl_xor(part, 1, 64);
+        part += __shfl_xor(part, 2, 64);
+        part += __shfl_xor(part, 4, 64);
+        if (ch == 0 && idx < RPAD * 8) {
+            del_s[row] = part;
+            lse_s[row] = row < L ? lse[row] : 0.f;
+        }
     }
 }
 
@@ -87,7 +121,6 @@ template <int TP, int RP>
 __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnK a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(VK_LDS char*)smem;
-    constexpr int PADS[2] = {TP, RP};
     constexpr int NKT[2] = {TP / 16, RP / 16};
     const uint32_t kimg[2] = {lds0, lds0 + TP * 128};
     const uint32_t vimg[2] = {lds0 + (TP + RP) * 128, lds0 + (TP + RP) * 128 + TP * 128};
@@ -95,12 +128,20 @@ __global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnK a) {
     const int b = blockIdx.x / a.nh, h = blockIdx.x - b * a.nh;
     const int g = lane >> 4, lq = lane & 15;
 
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        if (a.gate[0][m] || a.gate[1][m]) {
-            stage_img(kimg[m], a.k[m] + ((size_t)b * a.L[m]) * a.ld[m] + h * DH, a.ld[m], a.L[m], PADS[m], tid, blockDim.x);
-            stage_img(vimg[m], a.v[m] + ((size_t)b * a.L[m]) * a.ld[m] + h * DH, a.ld[m], a.L[m], PADS[m], tid, blockDim.x);
+    {
+        const int nthr = blockDim.x;
+        const bool k0 = a.gate[0][0] || a.gate[1][0], k1 = a.gate[0][1] || a.gate[1][1];
+        u32x4 rk0[StagePieces<TP>::N], rv0[StagePieces<TP>::N], rk1[StagePieces<RP>::N], rv1[StagePieces<RP>::N];
+        if (k0) {
+            stage_load<TP>(rk0, a.k[0] + ((size_t)b * a.L[0]) * a.ld[0] + h * DH, a.ld[0], a.L[0], tid, nthr);
+            stage_load<TP>(rv0, a.v[0] + ((size_t)b * a.L[0]) * a.ld[0] + h * DH, a.ld[0], a.L[0], tid, nthr);
         }
+        if (k1) {
+            stage_load<RP>(rk1, a.k[1] + ((size_t)b * a.L[1]) * a.ld[1] + h * DH, a.ld[1], a.L[1], tid, nthr);
+            stage_load<RP>(rv1, a.v[1] + ((size_t)b * a.L[1]) * a.ld[1] + h * DH, a.ld[1], a.L[1], tid, nthr);
+        }
+        if (k0) { stage_store<TP>(kimg[0], rk0, tid, nthr); stage_store<TP>(vimg[0], rv0, tid, nthr); }
+        if (k1) { stage_store<RP>(kimg[1], rk1, tid, nthr); stage_store<RP>(vimg[1], rv1, tid, nthr); }
     }
     __syncthreads();
 
@@ -217,35 +258,38 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         qact[m] = a.gate[m][0] || a.gate[m][1];
         kact[m] = a.gate[0][m] || a.gate[1][m];
     }
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-        const size_t row0 = (size_t)b * a.L[m];
-        if (kact[m]) {
-            stage_img(kimg[m], a.k[m] + row0 * a.ld[m] + h * DH, a.ld[m], a.L[m], PADS[m], tid, blockDim.x);
-            stage_img(vimg[m], a.v[m] + row0 * a.ld[m] + h * DH, a.ld[m], a.L[m], PADS[m], tid, blockDim.x);
+    {
+        const int nthr = blockDim.x;
+        const size_t r0 = (size_t)b * a.L[0], r1 = (size_t)b * a.L[1];
+        u32x4 rk0[StagePieces<TP>::N], rv0[StagePieces<TP>::N], rq0[StagePieces<TP>::N], rg0[StagePieces<TP>::N], ro0[StagePieces<TP>::N];
+        u32x4 rk1[StagePieces<RP>::N], rv1[StagePieces<RP>::N], rq1[StagePieces<RP>::N], rg1[StagePieces<RP>::N], ro1[StagePieces<RP>::N];
+        if (kact[0]) {
+            stage_load<TP>(rk0, a.k[0] + r0 * a.ld[0] + h * DH, a.ld[0], a.L[0], tid, nthr);
+            stage_load<TP>(rv0, a.v[0] + r0 * a.ld[0] + h * DH, a.ld[0], a.L[0], tid, nthr);
         }
-        if (qact[m]) {
-            stage_img(qimg[m], a.q[m] + row0 * a.ld[m] + h * DH, a.ld[m], a.L[m], PADS[m], tid, blockDim.x);
-            stage_img(gimg[m], a.dctx[m] + row0 * a.ldo[m] + h * DH, a.ldo[m], a.L[m], PADS[m], tid, blockDim.x);
-            // delta[q] = sum_d dO[q][d] * O[q][d] (8 lanes per row), lse copy
-            for (int idx = tid; idx < PADS[m] * 8; idx += blockDim.x) {
-                const int row = idx >> 3, ch = idx & 7;
-                float part = 0.f;
-                if (row < a.L[m]) {
-                    const u32x4 dv = *(const u32x4*)(a.dctx[m] + (row0 + row) * a.ldo[m] + h * DH + ch * 8);
-                    const u32x4 ov = *(const u32x4*)(a.ctx[m] + (row0 + row) * a.ldo[m] + h * DH + ch * 8);
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        part += bf2f(dv[i] & 0xFFFF) * bf2f(ov[i] & 0xFFFF) + bf2f(dv[i] >> 16) * bf2f(ov[i] >> 16);
-                }
-                part += __shfl_xor(part, 1, 64);
-                part += __shfl_xor(part, 2, 64);
-                part += __shfl_xor(part, 4, 64);
-                if (ch == 0) {
-                    del_s[rbase[m] + row] = part;
-                    lse_s[rbase[m] + row] = row < a.L[m] ? a.lse[m][((size_t)b * a.nh + h) * a.L[m] + row] : 0.f;
-                }
-            }
+        if (qact[0]) {
+            stage_load<TP>(rq0, a.q[0] + r0 * a.ld[0] + h * DH, a.ld[0], a.L[0], tid, nthr);
+            stage_load<TP>(rg0, a.dctx[0] + r0 * a.ldo[0] + h * DH, a.ldo[0], a.L[0], tid, nthr);
+            stage_load<TP>(ro0, a.ctx[0] + r0 * a.ldo[0] + h * DH, a.ldo[0], a.L[0], tid, nthr);
+        }
+        if (kact[1]) {
+            stage_load<RP>(rk1, a.k[1] + r1 * a.ld[1] + h * DH, a.ld[1], a.L[1], tid, nthr);
+            stage_load<RP>(rv1, a.v[1] + r1 * a.ld[1] + h * DH, a.ld[1], a.L[1], tid, nthr);
+        }
+        if (qact[1]) {
+            stage_load<RP>(rq1, a.q[1] + r1 * a.ld[1] + h * DH, a.ld[1], a.L[1], tid, nthr);
+            stage_load<RP>(rg1, a.dctx[1] + r1 * a.ldo[1] + h * DH, a.ldo[1], a.L[1], tid, nthr);
+            stage_load<RP>(ro1, a.ctx[1] + r1 * a.ldo[1] + h * DH, a.ldo[1], a.L[1], tid, nthr);
+        }
+        if (kact[0]) { stage_store<TP>(kimg[0], rk0, tid, nthr); stage_store<TP>(vimg[0], rv0, tid, nthr); }
+        if (qact[0]) {
+            stage_store<TP>(qimg[0], rq0, tid, nthr); stage_store<TP>(gimg[0], rg0, tid, nthr);
+            delta_rows<TP>(rg0, ro0, del_s + rbase[0], lse_s + rbase[0], a.lse[0] + ((size_t)b * a.nh + h) * a.L[0], a.L[0], tid, nthr);
+        }
+        if (kact[1]) { stage_store<RP>(kimg[1], rk1, tid, nthr); stage_store<RP>(vimg[1], rv1, tid, nthr); }
+        if (qact[1]) {
+            stage_store<RP>(qimg[1], rq1, tid, nthr); stage_store<RP>(gimg[1], rg1, tid, nthr);
+            delta_rows<RP>(rg1, ro1, del_s + rbase[1], lse_s + rbase[1], a.lse[1] + ((size_t)b * a.nh + h) * a.L[1], a.L[1], tid, nthr);
         }
     }
     __syncthreads();
@@ -412,7 +456,7 @@ static int fill(AttnK& k, const vk_attn_args* a, const vk_attn_bwd_args* bw) {
 template <int TP, int RP>
 static int launch_fwd(const AttnK& k, int nq_tiles, hipStream_t s) {
     const int lds = 2 * (TP + RP) * 128;
-    int waves = nq_tiles < 1 ? 1 : (nq_tiles > 8 ? 8 : nq_tiles);
+    int waves = nq_tiles < 4 ? 4 : (nq_tiles > 8 ? 8 : nq_tiles);      // staging is sized for >= 256 threads
     hipLaunchKernelGGL((attn_fwd_kernel<TP, RP>), dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
     return check_launch("vk_gated_attn_fwd");
 }
@@ -426,13 +470,13 @@ static int launch_bwd(const AttnK& k, int ntasks, hipStream_t s) {
         auto kern = attn_bwd_kernel<TP, RP, 3>;
         static bool once = false;
         if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
-        int waves = ntasks < 1 ? 1 : (ntasks > 5 ? 5 : ntasks);
+        int waves = ntasks < 4 ? 4 : (ntasks > 5 ? 5 : ntasks);
         hipLaunchKernelGGL(kern, dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
     } else {
         auto kern = attn_bwd_kernel<TP, RP, 2>;
         static bool once = false;
         if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
-        int waves = ntasks < 1 ? 1 : (ntasks > g_attn_bwd_waves ? g_attn_bwd_waves : ntasks);
+        int waves = g_attn_bwd_waves < 4 ? 4 : (ntasks > g_attn_bwd_waves ? g_attn_bwd_waves : (ntasks < 4 ? 4 : ntasks));      // staging is sized for >= 256 threads
         hipLaunchKernelGGL(kern, dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
     }
     return check_launch("vk_gated_attn_bwd");
