@@ -101,6 +101,17 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
             for (int j = 0; j < TJ; ++j)
                 b4[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rb, (uint32_t)(n_base + j * 16 + gq * 4) * 4u, 0, 0));
         }
+        // the residual / multiplier operand of the whole wave tile is requested up front: one L2 round trip instead of
+        // one per row of tiles (2 VGPRs per tile; the K loop's fragment registers are free by now)
+        u32x2 rall[USE_R ? TI : 1][TJ];
+        if (USE_R) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i) {
+                const char* rrow = Rp + ((size_t)(m_base + i * 16 + lr) * ldr + (size_t)(n_base + gq * 4)) * 2;
+#pragma unroll
+                for (int j = 0; j < TJ; ++j) rall[i][j] = *(const u32x2*)(rrow + j * 32);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
             __builtin_amdgcn_sched_barrier(0);
@@ -110,9 +121,8 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
             u32x2 rv[TJ];
             f32x4 cv[TJ];
             if (USE_R) {
-                const char* rrow = Rp + ((size_t)m * ldr + (size_t)(n_base + gq * 4)) * 2;
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) rv[j] = *(const u32x2*)(rrow + j * 32);
+                for (int j = 0; j < TJ; ++j) rv[j] = rall[i][j];
             }
             if (EPI == VK_EPI_F32_ACC) {
 #pragma unroll
