@@ -148,6 +148,37 @@ def write_ctrl(BertConfig, Model):
         del model, sd
 
 
+def write_hf_remap(BertConfig, Model):
+    """What the reference's from_pretrained(..., from_hf=True) (volta/utils.py:458-498) makes of a HuggingFace-layout
+    BERT checkpoint: per model key the checksum of the tensor that landed there + the loader's missing / unexpected lists."""
+    import json, tempfile
+    cd = dict(tiny_configs()["tiny_vilbert"], bert_layer2attn_sublayer={"0": 0, "1": 2, "2": 6}, bert_layer2ff_sublayer={"0": 1, "1": 3, "2": 7})
+    for tag, with_prefix in (("hf_remap_prefixed", True), ("hf_remap_bare", False)):
+        cfg = R.RefConfig(cd)
+        hf = R.hf_style_bert_state_dict(cfg, n_layers=3, seed=5, with_prefix=with_prefix)
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "pytorch_model.bin")
+            torch.save(hf, path)
+            torch.manual_seed(0)
+            model, info = Model.from_pretrained(path, config=BertConfig.from_dict(cd), from_hf=True, output_loading_info=True, default_gpu=False)
+        sd = model.state_dict()
+        keys = list(sd.keys())
+        miss = set(info["missing_keys"])
+        if with_prefix:
+            loaded = [k for k in keys if k not in miss]
+        else:       # only model.bert was loaded (utils.py:513-516): the loader's key lists are relative to it
+            loaded = [k for k in keys if k.startswith("bert.") and k[len("bert."):] not in miss]
+        blob = {"cfg_json": np.array(json.dumps(cd)), "with_prefix": np.array([int(with_prefix)]),
+                "missing": np.array(sorted(info["missing_keys"])), "unexpected": np.array(sorted(info["unexpected_keys"])),
+                "loaded_keys": np.array(loaded),
+                "loaded_sum": np.array([float(sd[k].double().sum()) for k in loaded]),
+                "loaded_first": np.array([float(sd[k].reshape(-1)[0]) for k in loaded]),
+                "training": np.array([int(model.training)])}
+        path = os.path.join(OUT, tag + ".npz")
+        np.savez_compressed(path, **blob)
+        print(tag, len(loaded), "loaded,", len(info["missing_keys"]), "missing,", len(info["unexpected_keys"]), "unexpected", os.path.getsize(path) // 1024, "KB")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -158,3 +189,5 @@ if __name__ == "__main__":
         write_tiny(BertConfig, Model)
     if which in ("all", "ctrl"):
         write_ctrl(BertConfig, Model)
+    if which in ("all", "hf"):
+        write_hf_remap(BertConfig, Model)

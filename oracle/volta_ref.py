@@ -688,3 +688,50 @@ def forward_from_batch(sd, cfg, b, **kw):
     return pretrain_forward(sd, cfg, b["input_ids"], b["image_feat"], b["image_loc"], b["segment_ids"],
                             b["input_mask"], b["image_mask"], b["lm_label_ids"], b["image_label"],
                             b["image_cls"], b["is_match"], **kw)
+
+
+def hf_style_bert_state_dict(cfg, n_layers, seed=0, with_prefix=True):
+    """A BERT checkpoint in the HuggingFace key layout (`bert.encoder.layer.N.attention.self.query.weight`, old-style
+    `LayerNorm.gamma/beta` in the embeddings, a pooler the VOLTA models do not have), filled by a counter-based
+    generator: the input of the `from_hf=True` branch of the reference loader (volta/utils.py:458-498)."""
+    H, I, V = cfg.hidden_size, cfg.intermediate_size, cfg.vocab_size
+    pre = "bert." if with_prefix else ""
+    shapes = {
+        pre + "embeddings.word_embeddings.weight": (V, H),
+        pre + "embeddings.position_embeddings.weight": (cfg.max_position_embeddings, H),
+        pre + "embeddings.token_type_embeddings.weight": (cfg.type_vocab_size, H),
+        pre + "embeddings.LayerNorm.gamma": (H,),
+        pre + "embeddings.LayerNorm.beta": (H,),
+        pre + "pooler.dense.weight": (H, H),
+        pre + "pooler.dense.bias": (H,),
+    }
+    for n in range(n_layers):
+        b = pre + "encoder.layer.%d." % n
+        for nm in ("query", "key", "value"):
+            shapes[b + "attention.self.%s.weight" % nm] = (H, H)
+            shapes[b + "attention.self.%s.bias" % nm] = (H,)
+        shapes[b + "attention.output.dense.weight"] = (H, H)
+        shapes[b + "attention.output.dense.bias"] = (H,)
+        shapes[b + "attention.output.LayerNorm.weight"] = (H,)
+        shapes[b + "attention.output.LayerNorm.bias"] = (H,)
+        shapes[b + "intermediate.dense.weight"] = (I, H)
+        shapes[b + "intermediate.dense.bias"] = (I,)
+        shapes[b + "output.dense.weight"] = (H, I)
+        shapes[b + "output.dense.bias"] = (H,)
+        shapes[b + "output.LayerNorm.weight"] = (H,)
+        shapes[b + "output.LayerNorm.bias"] = (H,)
+    if with_prefix:
+        shapes["cls.predictions.bias"] = (V,)
+        shapes["cls.predictions.transform.dense.weight"] = (H, H)
+        shapes["cls.predictions.transform.dense.bias"] = (H,)
+        shapes["cls.predictions.transform.LayerNorm.gamma"] = (H,)
+        shapes["cls.predictions.transform.LayerNorm.beta"] = (H,)
+        shapes["cls.predictions.decoder.weight"] = (V, H)
+        shapes["cls.seq_relationship.weight"] = (2, H)
+    sd = {}
+    for i, (name, shape) in enumerate(shapes.items()):
+        g = torch.Generator().manual_seed(seed * 7919 + i)
+        sd[name] = 0.1 * torch.randn(shape, generator=g) + 0.01 * i
+    if with_prefix:
+        sd["cls.predictions.decoder.weight"] = sd[pre + "embeddings.word_embeddings.weight"]      # tied in BERT
+    return sd

@@ -67,27 +67,63 @@ class PreTrainedModel(nn.Module):
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, *model_args, config=None, state_dict=None, **kwargs):
-        """Local directory / file branch of the reference loader (volta/utils.py:419-430, 455-550).  Named
-        archives would need the network (utils.py:417-418) and are refused."""
+        """Local directory / file branch of the reference loader (volta/utils.py:404-550): old `gamma` / `beta` names,
+        the HuggingFace-BERT key renumbering of `from_hf=True` (`bert_layer2attn_sublayer` / `bert_layer2ff_sublayer`,
+        utils.py:475-498), base-model checkpoints without the `bert.` prefix (utils.py:513-521), tied decoder, eval mode,
+        `output_loading_info`.  Named archives would need the network (utils.py:417-418) and are refused."""
         kwargs.pop("default_gpu", None)
+        kwargs.pop("cache_dir", None)
         from_hf = kwargs.pop("from_hf", False)
+        output_loading_info = kwargs.pop("output_loading_info", False)
+        if kwargs.pop("from_tf", False):
+            raise NotImplementedError("TensorFlow checkpoints (volta/utils.py:424-426) are not supported")
+        assert config is not None
         path = pretrained_model_name_or_path
-        if os.path.isdir(path):
+        if path is not None and os.path.isdir(path):
             path = os.path.join(path, "pytorch_model.bin")
         if state_dict is None:
-            if not os.path.isfile(path):
+            if path is None or not os.path.isfile(path):
                 raise EnvironmentError("'%s' is not a local checkpoint; downloading named archives is not available "
                                        "offline (volta/utils.py:417-418)" % pretrained_model_name_or_path)
             state_dict = torch.load(path, map_location="cpu")
-        if from_hf:
-            raise NotImplementedError("HF-BERT key renumbering (volta/utils.py:475-498) is a 'next' item (SURVEY.md 8f-1)")
         model = cls(config, *model_args, **kwargs)
         sd = {}
-        for k, v in state_dict.items():
-            k = k.replace("gamma", "weight") if k.endswith("gamma") else k
-            k = k.replace("beta", "bias") if k.endswith("beta") else k
-            sd[k[len("module."):] if k.startswith("module.") else k] = v
-        missing, unexpected = model.load_state_dict(sd, strict=False)
+        for k, v in state_dict.items():                       # old LayerNorm parameter names (utils.py:461-472)
+            if "gamma" in k:
+                k = k.replace("gamma", "weight")
+            if "beta" in k:
+                k = k.replace("beta", "bias")
+            sd[k[len("module."):] if k.startswith("module.") else k] = v     # (DDP-wrapped saves; train_utils.py:326-330)
+        if from_hf:                                           # one BERT layer -> one attention + one FF sub-layer
+            a2s, f2s = config.bert_layer2attn_sublayer, config.bert_layer2ff_sublayer
+            renames = []
+            for k in sd:
+                if ".layer." not in k:
+                    continue
+                num = int(k.split(".layer.")[-1].split(".")[0])
+                nk = None
+                if ".attention." in k:
+                    nk = k.replace(".layer.%d.attention." % num, ".layer.%d.attention_" % a2s.get(str(num), num))
+                elif ".intermediate." in k:
+                    nk = k.replace(".layer.%d.intermediate." % num, ".layer.%d.intermediate." % f2s.get(str(num), num))
+                elif ".output." in k:
+                    nk = k.replace(".layer.%d.output." % num, ".layer.%d.output." % f2s.get(str(num), num))
+                if nk:
+                    renames.append((k, nk, num))
+            for k, nk, _ in sorted(renames, key=lambda x: x[2], reverse=True):      # highest layer first: no clobbering
+                sd[nk] = sd.pop(k)
+        # derived model <- base checkpoint, or base model <- derived checkpoint (utils.py:511-521)
+        prefix = cls.base_model_prefix + "."
+        has_prefix = any(k.startswith(prefix) for k in sd)
+        target, rel = model, ""
+        if hasattr(model, cls.base_model_prefix) and not has_prefix:
+            target = getattr(model, cls.base_model_prefix)
+        elif not hasattr(model, cls.base_model_prefix) and has_prefix:
+            rel = prefix
+        if rel:
+            sd = {k[len(rel):]: v for k, v in sd.items() if k.startswith(rel)}
+        res = target.load_state_dict(sd, strict=False)
+        missing, unexpected = list(res.missing_keys), list(res.unexpected_keys)
         if missing:
             print("Weights of {} not initialized from pretrained model: {}".format(cls.__name__, missing))
         if unexpected:
@@ -95,6 +131,8 @@ class PreTrainedModel(nn.Module):
         if hasattr(model, "tie_weights"):
             model.tie_weights()
         model.eval()
+        if output_loading_info:
+            return model, {"missing_keys": missing, "unexpected_keys": unexpected, "error_msgs": []}
         return model
 
 
@@ -214,6 +252,8 @@ class BertForVLPreTraining(PreTrainedModel):
         for mod in self.modules():
             if mod is not self and isinstance(mod, PreTrainedModel):
                 mod.__dict__["_root"] = self
+        for p in self.parameters():            # lets an optimizer find (and materialize) its model before the first forward,
+            p._vk_owner = self                 # e.g. AdamW.load_state_dict() in the reference's resume() order
 
     def tie_weights(self):
         self._tie_or_clone_weights(self.cls.predictions.decoder, self.bert.embeddings.word_embeddings)

@@ -103,6 +103,50 @@ class AdamW(Optimizer):
         arena.shadow_version = arena.master._version      # the kernel refreshed the bf16 copies itself
         return loss
 
+    # ---- checkpoint interchange (volta/train_utils.py:295-340 saves optimizer.state_dict() of pytorch_transformers'
+    # AdamW: per parameter {"step", "exp_avg", "exp_avg_sq"}, indexed in param_groups order)
+    def _spans(self):
+        arena = self._fused["arena"]
+        byptr = {p.data_ptr(): n for n, p in arena.params.items()}
+        out = []
+        for g in self.param_groups:
+            for p in g["params"]:
+                n = byptr[p.data_ptr()]
+                numel = 1
+                for d in arena.shape[n]:
+                    numel *= d
+                out.append((arena.offset[n], numel, tuple(arena.shape[n])))
+        return out
+
+    def state_dict(self):
+        sd = super().state_dict()
+        if self._fused is not None and self._fused["step"] > 0:
+            f = self._fused
+            sd["state"] = {i: {"step": f["step"], "exp_avg": f["m"][o:o + n].view(shape).clone(), "exp_avg_sq": f["v"][o:o + n].view(shape).clone()}
+                           for i, (o, n, shape) in enumerate(self._spans())}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state = state_dict.get("state", {})
+        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
+        if not state:
+            return
+        if self._fused is None:
+            self._setup()
+        f = self._fused
+        spans = self._spans()
+        if len(state) != len(spans):
+            raise ValueError("volta_amd.AdamW.load_state_dict: the checkpoint holds %d parameter states, the optimizer %d parameters" % (len(state), len(spans)))
+        steps = set()
+        for i, (o, n, shape) in enumerate(spans):
+            st = state[i] if i in state else state[str(i)]
+            f["m"][o:o + n].copy_(st["exp_avg"].reshape(-1))
+            f["v"][o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(st["step"]))
+        if len(steps) != 1:
+            raise ValueError("volta_amd.AdamW.load_state_dict: parameters at different step counts %s (one fused launch updates all of them)" % sorted(steps))
+        f["step"] = steps.pop()
+
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
             for p in g["params"]:
