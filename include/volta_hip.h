@@ -111,6 +111,8 @@ typedef struct vk_ln_args {
     vk_drop_rows seg[2];
 } vk_ln_args;
 int vk_ln_fwd(const vk_ln_args* a, vk_stream_t s);
+/* Two independent jobs of equal H in ONE launch (text and vision stream of a sub-layer); b may be NULL. */
+int vk_ln_fwd_pair(const vk_ln_args* a, const vk_ln_args* b, vk_stream_t s);
 
 typedef struct vk_ln_bwd_args {
     const void* dy;        /* bf16 [M, H] */
@@ -135,6 +137,7 @@ typedef struct vk_ln_bwd_args {
 } vk_ln_bwd_args;
 int vk_ln_bwd_partial_rows(int M);
 int vk_ln_bwd(const vk_ln_bwd_args* a, vk_stream_t s);
+int vk_ln_bwd_pair(const vk_ln_bwd_args* a, const vk_ln_bwd_args* b, vk_stream_t s);
 /* dgamma / dbeta from the per-workgroup partial records of a vk_ln_bwd issued with accumulate bit 1 set: off the
    critical path of the backward pass (the parameters' gradients are only needed by the optimizer / all-reduce). */
 int vk_ln_bwd_finalize(const vk_ln_bwd_args* a, vk_stream_t s);
@@ -318,7 +321,8 @@ int vk_mul_bf16(const void* a, const void* b, void* out, int64_t n, const int32_
  * the reference walks a Python module tree and autograd graph every step (volta/encoders.py:868-881). */
 enum {
     VK_OP_GEMM = 1,      /* a = vk_gemm_problem[i2], i0 = layout, i1 = epilogue */
-    VK_OP_LN_FWD, VK_OP_LN_BWD, VK_OP_ATTN_FWD,
+    VK_OP_LN_FWD, VK_OP_LN_BWD,   /* a = args, b = args of a second job sharing the launch or NULL */
+    VK_OP_ATTN_FWD,
     VK_OP_ATTN_BWD,      /* a = vk_attn_args, b = vk_attn_bwd_args */
     VK_OP_EMBED_FWD, VK_OP_EMBED_BWD, VK_OP_XENT_FWD,
     VK_OP_XENT_BWD,      /* a = vk_xent_args, b = dlogits, i0 = ldd, c = gscale */

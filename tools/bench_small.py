@@ -60,7 +60,7 @@ if __name__ == "__main__":
     ln(9472)
     L.lib.vk_attn_set_bwd_occupancy.argtypes = [ctypes.c_int]
     L.lib.vk_attn_set_bwd_waves.argtypes = [ctypes.c_int]
-    for wv in (8, 4, 5, 6, 3):
+    for wv in (4, 8, 5):
         L.lib.vk_attn_set_bwd_waves(wv)
         print("--- attn bwd waves per workgroup", wv)
         attn([[1, 0], [0, 0]])

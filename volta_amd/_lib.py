@@ -166,11 +166,13 @@ _sig("vk_memset_async", C.c_int, c_p, C.c_int, C.c_int64, c_p)
 _sig("vk_run_ops", C.c_int, C.POINTER(Op), C.c_int, c_p)
 _sig("vk_run_ops_timed", C.c_int, C.POINTER(Op), C.c_int, c_p, C.POINTER(C.c_float))
 _sig("vk_ln_bwd_finalize", C.c_int, C.POINTER(LnBwdArgs), c_p)
+_sig("vk_ln_fwd_pair", C.c_int, C.POINTER(LnArgs), C.POINTER(LnArgs), c_p)
+_sig("vk_ln_bwd_pair", C.c_int, C.POINTER(LnBwdArgs), C.POINTER(LnBwdArgs), c_p)
 _sig("vk_side_join", C.c_int, c_p)
 _sig("vk_side_enable", None, C.c_int)
 
 EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_cast_f32_bf16", "vk_gemm_grouped",
-           "vk_ln_fwd", "vk_ln_bwd_partial_rows", "vk_ln_bwd", "vk_ln_bwd_finalize", "vk_gated_attn_fwd", "vk_gated_attn_bwd",
+           "vk_ln_fwd", "vk_ln_fwd_pair", "vk_ln_bwd_partial_rows", "vk_ln_bwd", "vk_ln_bwd_pair", "vk_ln_bwd_finalize", "vk_gated_attn_fwd", "vk_gated_attn_bwd",
            "vk_embed_sum_fwd", "vk_embed_sum_bwd", "vk_rows32", "vk_loc_linear_fwd", "vk_loc_linear_bwd",
            "vk_add_dropout", "vk_colsum_bf16", "vk_vlbert_prep_fwd", "vk_vlbert_maskgrad", "vk_rowgroup_sum_bf16",
            "vk_relu_bwd_bf16", "vk_copy_async", "vk_select_rows", "vk_gather_rows", "vk_scatter_rows_add", "vk_xent_fwd",

@@ -112,8 +112,8 @@ static int run_one(const vk_op& o, int i, vk_stream_t s) {
         int rc = 0;
         switch (o.kind) {
             case VK_OP_GEMM: rc = vk_gemm_grouped(o.i0, o.i1, (const vk_gemm_problem*)o.a, o.i2, s); break;
-            case VK_OP_LN_FWD: rc = vk_ln_fwd((const vk_ln_args*)o.a, s); break;
-            case VK_OP_LN_BWD: rc = vk_ln_bwd((const vk_ln_bwd_args*)o.a, s); break;
+            case VK_OP_LN_FWD: rc = vk_ln_fwd_pair((const vk_ln_args*)o.a, (const vk_ln_args*)o.b, s); break;
+            case VK_OP_LN_BWD: rc = vk_ln_bwd_pair((const vk_ln_bwd_args*)o.a, (const vk_ln_bwd_args*)o.b, s); break;
             case VK_OP_LN_FINALIZE: rc = vk_ln_bwd_finalize((const vk_ln_bwd_args*)o.a, s); break;
             case VK_OP_ATTN_FWD: rc = vk_gated_attn_fwd((const vk_attn_args*)o.a, s); break;
             case VK_OP_ATTN_BWD: rc = vk_gated_attn_bwd((const vk_attn_args*)o.a, (const vk_attn_bwd_args*)o.b, s); break;

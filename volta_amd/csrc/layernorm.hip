@@ -31,10 +31,38 @@ __device__ __forceinline__ void store4(uint16_t* p, const float (&v)[4]) {
     *(u32x2*)p = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
 }
 
+// One launch serves up to two independent jobs (the text and the vision stream of a sub-layer): workgroups
+// [0, nb0) belong to job a0, the rest to job a1.  Each job is a launch-latency-sized problem (30-60 MB), so sharing
+// the launch saves one ramp and fills the chip better than two half-empty grids.
+// (The job's argument block is read from the kernel-argument segment at a workgroup-uniform offset: selecting between
+// two by-value structs through a reference makes hipcc spill both to scratch.)
+template <typename T> struct JobPair { T job[2]; int32_t nb0; };
+template <typename T>
+__device__ __forceinline__ T load_job(int which) {
+    static_assert(sizeof(T) % 8 == 0 && alignof(T) == 8, "argument blocks are copied in 8-byte words");
+    typedef __attribute__((ext_vector_type(16))) uint32_t w16;
+    typedef __attribute__((ext_vector_type(2))) uint32_t w2;
+    typedef __attribute__((address_space(4))) const char* kptr;
+    const kptr base = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + (which ? sizeof(T) : 0);
+    constexpr int N16 = sizeof(T) / 64, N2 = (sizeof(T) % 64) / 8;
+    struct { w16 a[N16 ? N16 : 1]; w2 b[N2 ? N2 : 1]; } buf;       // wide scalar loads (s_load_dwordx16): one wait, not one per word
+#pragma unroll
+    for (int i = 0; i < N16; ++i) buf.a[i] = *(__attribute__((address_space(4))) const w16*)(base + 64 * i);
+#pragma unroll
+    for (int i = 0; i < N2; ++i) buf.b[i] = *(__attribute__((address_space(4))) const w2*)(base + 64 * N16 + 8 * i);
+    T out;
+    __builtin_memcpy(&out, &buf.a[0], 64 * N16);
+    __builtin_memcpy((char*)&out + 64 * N16, &buf.b[0], 8 * N2);
+    return out;
+}
+
 template <int NCH>
-__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(vk_ln_args a) {
+__global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const JobPair<vk_ln_args> jp) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.x * 4 + wave;
+    const int nb0 = jp.nb0;
+    const bool second = (int)blockIdx.x >= nb0;
+    const vk_ln_args a = load_job<vk_ln_args>(second);
+    const int row = (second ? (int)blockIdx.x - nb0 : (int)blockIdx.x) * 4 + wave;
     const int Mrows = a.dyn ? min(*a.dyn, a.M) : a.M;
     if (row >= Mrows) return;
     const int H = a.H;
@@ -112,8 +140,12 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(vk_ln_args a) {
 }
 
 template <int NCH>
-__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(vk_ln_bwd_args a) {
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const JobPair<vk_ln_bwd_args> jp) {
     __shared__ float red[4][2][NCH * 256];
+    const int nb0 = jp.nb0;
+    const bool second = (int)blockIdx.x >= nb0;
+    const vk_ln_bwd_args a = load_job<vk_ln_bwd_args>(second);
+    const int blk = second ? (int)blockIdx.x - nb0 : (int)blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int H = a.H;
     const bool drop_on = a.drop.threshold != 0;
@@ -132,7 +164,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(vk_ln_bwd_args a) {
     u32x2 rdy[RPW][NCH], rz[RPW][NCH];
 #pragma unroll
     for (int it = 0; it < RPW; ++it) {
-        const int row = blockIdx.x * LN_BWD_ROWS + it * 4 + wave;
+        const int row = blk * LN_BWD_ROWS + it * 4 + wave;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c = j * 256 + lane * 4;
@@ -146,7 +178,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(vk_ln_bwd_args a) {
     }
 #pragma unroll
     for (int it = 0; it < RPW; ++it) {
-        const int row = blockIdx.x * LN_BWD_ROWS + it * 4 + wave;
+        const int row = blk * LN_BWD_ROWS + it * 4 + wave;
         if (row >= Mrows) break;
         uint32_t dsite;
         const uint32_t drow = drop_row(a.seg, a.split_row, row, dsite);
@@ -212,7 +244,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(vk_ln_bwd_args a) {
             red[wave][1][j * 256 + lane * 4 + r] = pb[j][r];
         }
     __syncthreads();
-    float* out = a.partial + (size_t)blockIdx.x * 2 * H;
+    float* out = a.partial + (size_t)blk * 2 * H;
     for (int i = threadIdx.x; i < 2 * NCH * 256; i += LN_THREADS) {
         const int which = i / (NCH * 256), c = i - which * NCH * 256;
         if (c < H) out[which * H + c] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
@@ -239,50 +271,71 @@ __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* part
 
 }  // namespace vk
 
-extern "C" int vk_ln_fwd(const vk_ln_args* a, vk_stream_t stream) {
+static int ln_check(int H, int maxH, const char* who) {
+    if (H % 4 || H > maxH || H <= 0) return vk::set_error("%s: H=%d must be a multiple of 4, <= %d", who, H, maxH);
+    return 0;
+}
+
+extern "C" int vk_ln_fwd_pair(const vk_ln_args* a, const vk_ln_args* b, vk_stream_t stream) {
     using namespace vk;
-    if (a->H % 4 || a->H > 2048 || a->H <= 0) return set_error("vk_ln_fwd: H=%d must be a multiple of 4, <= 2048", a->H);
-    if (a->M <= 0) return 0;
+    if (ln_check(a->H, 2048, "vk_ln_fwd")) return -1;
+    if (b && (b->H != a->H || a->dyn || b->dyn)) return set_error("vk_ln_fwd_pair: both jobs need the same H and static row counts");
+    const int nb0 = a->M > 0 ? (a->M + 3) / 4 : 0, nb1 = (b && b->M > 0) ? (b->M + 3) / 4 : 0;
+    if (nb0 + nb1 == 0) return 0;
     const int nch = (a->H + 255) / 256;
-    dim3 grid((a->M + 3) / 4), block(LN_THREADS);
+    dim3 grid(nb0 + nb1), block(LN_THREADS);
     hipStream_t s = (hipStream_t)stream;
+    JobPair<vk_ln_args> jp;
+    jp.job[0] = *a;
+    jp.job[1] = b ? *b : *a;
+    jp.nb0 = nb0;
     switch (nch) {
-        case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, s, *a); break;
-        case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, s, *a); break;
-        case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, s, *a); break;
-        case 4: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, *a); break;
-        default: hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, s, *a); break;
+        case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, s, jp); break;
+        case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, s, jp); break;
+        case 3: hipLaunchKernelGGL(ln_fwd_kernel<3>, grid, block, 0, s, jp); break;
+        case 4: hipLaunchKernelGGL(ln_fwd_kernel<4>, grid, block, 0, s, jp); break;
+        default: hipLaunchKernelGGL(ln_fwd_kernel<8>, grid, block, 0, s, jp); break;
     }
     return check_launch("vk_ln_fwd");
 }
 
+extern "C" int vk_ln_fwd(const vk_ln_args* a, vk_stream_t stream) { return vk_ln_fwd_pair(a, nullptr, stream); }
+
 extern "C" int vk_ln_bwd_partial_rows(int M) { return (M + vk::LN_BWD_ROWS - 1) / vk::LN_BWD_ROWS; }
 
-extern "C" int vk_ln_bwd(const vk_ln_bwd_args* a, vk_stream_t stream) {
+static void ln_finalize_launch(const vk_ln_bwd_args* a, hipStream_t s) {
+    hipLaunchKernelGGL(vk::ln_bwd_finalize_kernel, dim3((2 * a->H + 63) / 64), dim3(1024), 0, s, a->partial, vk_ln_bwd_partial_rows(a->M), a->H,
+                       a->dgamma, a->dbeta, a->accumulate & 1);
+}
+
+extern "C" int vk_ln_bwd_pair(const vk_ln_bwd_args* a, const vk_ln_bwd_args* b, vk_stream_t stream) {
     using namespace vk;
-    if (a->H % 4 || a->H > 1024 || a->H <= 0) return set_error("vk_ln_bwd: H=%d must be a multiple of 4, <= 1024", a->H);
-    if (a->M <= 0) return 0;
+    if (ln_check(a->H, 1024, "vk_ln_bwd")) return -1;
+    if (b && (b->H != a->H || a->dyn || b->dyn)) return set_error("vk_ln_bwd_pair: both jobs need the same H and static row counts");
+    const int nb0 = a->M > 0 ? vk_ln_bwd_partial_rows(a->M) : 0, nb1 = (b && b->M > 0) ? vk_ln_bwd_partial_rows(b->M) : 0;
+    if (nb0 + nb1 == 0) return 0;
     const int nch = (a->H + 255) / 256;
-    const int nblk = vk_ln_bwd_partial_rows(a->M);
-    dim3 grid(nblk), block(LN_THREADS);
+    dim3 grid(nb0 + nb1), block(LN_THREADS);
     hipStream_t s = (hipStream_t)stream;
+    JobPair<vk_ln_bwd_args> jp;
+    jp.job[0] = *a;
+    jp.job[1] = b ? *b : *a;
+    jp.nb0 = nb0;
     switch (nch) {
-        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, *a); break;
-        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, *a); break;
-        case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, *a); break;
-        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, *a); break;
+        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, jp); break;
+        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, jp); break;
+        case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, jp); break;
+        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, jp); break;
     }
-    if (!(a->accumulate & 2))
-        hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * a->H + 63) / 64), dim3(1024), 0, s, a->partial, nblk, a->H,
-                           a->dgamma, a->dbeta, a->accumulate & 1);
+    if (nb0 && !(a->accumulate & 2)) ln_finalize_launch(a, s);
+    if (nb1 && !(b->accumulate & 2)) ln_finalize_launch(b, s);
     return check_launch("vk_ln_bwd");
 }
 
+extern "C" int vk_ln_bwd(const vk_ln_bwd_args* a, vk_stream_t stream) { return vk_ln_bwd_pair(a, nullptr, stream); }
+
 extern "C" int vk_ln_bwd_finalize(const vk_ln_bwd_args* a, vk_stream_t stream) {
-    using namespace vk;
     if (a->M <= 0) return 0;
-    const int nblk = vk_ln_bwd_partial_rows(a->M);
-    hipLaunchKernelGGL(ln_bwd_finalize_kernel, dim3((2 * a->H + 63) / 64), dim3(1024), 0, (hipStream_t)stream, a->partial, nblk, a->H,
-                       a->dgamma, a->dbeta, a->accumulate & 1);
-    return check_launch("vk_ln_bwd_finalize");
+    ln_finalize_launch(a, (hipStream_t)stream);
+    return vk::check_launch("vk_ln_bwd_finalize");
 }

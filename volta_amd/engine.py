@@ -715,24 +715,27 @@ class StepEngine:
         self.k(aa)
         f.append((L.OP_ATTN_FWD, 0, 0, 0, aa, None, None))
         self.gemm(f, L.NT, L.EPI_BF16, [self.prob(ctx[m], self.W(names[m]["o"] + ".weight"), d[m], self.st[m].M, H, H, H, H, H, bias=self.Pm(names[m]["o"] + ".bias")) for m in ms])
-        odrop = {}
+        odrop, lnf = {}, []
         for m in ms:
             odrop[m] = self.drop(cfg.hidden_dropout_prob if m == 0 else cfg.v_hidden_dropout_prob)
-            f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(d[m], x_in[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", y[m], d[m], mean[m], rstd[m], self.st[m].M, odrop[m]), None, None))
+            lnf.append(self.ln_args(d[m], x_in[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", y[m], d[m], mean[m], rstd[m], self.st[m].M, odrop[m]))
             self.x[m] = y[m]
+        f.append((L.OP_LN_FWD, 0, 0, 0, lnf[0], lnf[1] if len(lnf) > 1 else None, None))      # both streams in one launch
         # ------------- backward
         b = []
         dz, dd, dctx, dqkv, dxn, dxi = {}, {}, {}, {}, {}, {}
+        lnb = []
         for i, m in enumerate(ms):
             dxi[m], dxn[m] = self._dx_step(m)
             acc = 1 if (shared and i > 0) else 0
             par = self.sub_k % 2
             dz[m] = self.tmp("dz%d_%d" % (m, par), (self.st[m].M, H))
             dd[m] = self.tmp("dd%d_%d" % (m, par), (self.st[m].M, H)) if self.train else dz[m]
-            b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dxi[m], d[m], mean[m], rstd[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", dz[m],
-                                                              dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc, defer=True), None, None))
+            lnb.append(self.ln_bwd_args(dxi[m], d[m], mean[m], rstd[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", dz[m],
+                                        dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc, defer=True))
             dctx[m] = self.tmp("dctx%d" % m, (self.st[m].M, H))
             dqkv[m] = self.tmp("dqkv%d_%d" % (m, par), (self.st[m].M, 3 * H))
+        b.append((L.OP_LN_BWD, 0, 0, 0, lnb[0], lnb[1] if len(lnb) > 1 else None, None))
         self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dd[m], self.W(names[m]["o"] + ".weight"), dctx[m], self.st[m].M, H, H, H, H, H) for m in ms])
         ab = L.AttnBwdArgs()
         for m in ms:
@@ -765,22 +768,25 @@ class StepEngine:
         rstd = {m: self.buf(tag + "rstd%d" % m, (self.st[m].M,), torch.float32) for m in ms}
         self.gemm(f, L.NT, L.EPI_GELU, [self.prob(x_in[m], self.W(names[m]["up"] + ".weight"), h[m], self.st[m].M, I, H, H, H, I, bias=self.Pm(names[m]["up"] + ".bias"), C2=gp[m]) for m in ms])
         self.gemm(f, L.NT, L.EPI_BF16, [self.prob(h[m], self.W(names[m]["down"] + ".weight"), d[m], self.st[m].M, H, I, I, I, H, bias=self.Pm(names[m]["down"] + ".bias")) for m in ms])
-        odrop = {}
+        odrop, lnf = {}, []
         for m in ms:
             odrop[m] = self.drop(cfg.hidden_dropout_prob if m == 0 else cfg.v_hidden_dropout_prob)
-            f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(d[m], x_in[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", y[m], d[m], mean[m], rstd[m], self.st[m].M, odrop[m]), None, None))
+            lnf.append(self.ln_args(d[m], x_in[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", y[m], d[m], mean[m], rstd[m], self.st[m].M, odrop[m]))
             self.x[m] = y[m]
+        f.append((L.OP_LN_FWD, 0, 0, 0, lnf[0], lnf[1] if len(lnf) > 1 else None, None))      # both streams in one launch
         b = []
         dz, dd, du, dxn, dxi = {}, {}, {}, {}, {}
+        lnb = []
         for i, m in enumerate(ms):
             dxi[m], dxn[m] = self._dx_step(m)
             acc = 1 if (shared and i > 0) else 0
             par = self.sub_k % 2
             dz[m] = self.tmp("dz%d_%d" % (m, par), (self.st[m].M, H))
             dd[m] = self.tmp("dd%d_%d" % (m, par), (self.st[m].M, H)) if self.train else dz[m]
-            b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dxi[m], d[m], mean[m], rstd[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", dz[m],
-                                                              dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc, defer=True), None, None))
+            lnb.append(self.ln_bwd_args(dxi[m], d[m], mean[m], rstd[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", dz[m],
+                                        dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc, defer=True))
             du[m] = self.tmp("du%d_%d" % (m, par), (self.st[m].M, I))
+        b.append((L.OP_LN_BWD, 0, 0, 0, lnb[0], lnb[1] if len(lnb) > 1 else None, None))
         self.gemm(b, L.NN, L.EPI_MULR, [self.prob(dd[m], self.W(names[m]["down"] + ".weight"), du[m], self.st[m].M, I, H, H, I, I, R=gp[m], ldr=I) for m in ms])
         self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(du[m], self.W(names[m]["up"] + ".weight"), dxn[m], self.st[m].M, H, I, I, H, H, R=dz[m], ldr=H) for m in ms])
         self._wgrad(b, ms, shared, [lambda m: (dd[m], h[m], self.G(names[m]["down"] + ".weight"), self.G(names[m]["down"] + ".bias"), H, I, H, I),
