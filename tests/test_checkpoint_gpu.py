@@ -64,7 +64,7 @@ def test_save_resume_continues_bit_identically(tmp_path):
     _step(model2, opt2, sched2, batches[2])
     torch.cuda.synchronize()
     for k, v in model2.state_dict().items():
-        if "embeddings" in k:      # accumulated with fp32 atomics: summation order is not fixed
+        if "embeddings" in k or k == "cls.predictions.decoder.weight":      # tables (and the decoder tied to one): gradients accumulated with fp32 atomics, order not fixed
             assert float((v - want[k]).abs().max()) <= 1e-6, k
         else:
             assert torch.equal(v, want[k]), k
