@@ -91,11 +91,20 @@ __device__ __forceinline__ float group_sum(float v) {
     v += __shfl_xor(v, 16, 64);
     return v + __shfl_xor(v, 32, 64);
 }
-__device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {
-    bf16x8 r;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { r[i] = (short)f2bf(a[i]); r[4 + i] = (short)f2bf(b[i]); }
-    return r;
+__device__ __forceinline__ bf16x8 pack_pair(const f32x4& a, const f32x4& b) {      // 4 x v_cvt_pk_bf16_f32
+    const u32x4 w = {pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
+    return __builtin_bit_cast(bf16x8, w);
+}
+
+// word `sel` (0..3) of the u32x4 held by lane R of this lane's quad (4 consecutive lanes): DPP quad broadcasts + selects
+template <int R>
+__device__ __forceinline__ uint32_t quad_word(const u32x4& w, int sel) {
+    constexpr int ctrl = R * 0x55;       // quad_perm [R, R, R, R]
+    const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[0], ctrl, 0xF, 0xF, false);
+    const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[1], ctrl, 0xF, 0xF, false);
+    const uint32_t b2 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[2], ctrl, 0xF, 0xF, false);
+    const uint32_t b3 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)w[3], ctrl, 0xF, 0xF, false);
+    return sel == 0 ? b0 : sel == 1 ? b1 : sel == 2 ? b2 : b3;
 }
 
 struct AttnK {                       // kernel-side copy of vk_attn_args (+ backward pointers)
@@ -329,16 +338,22 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                             s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(qimg[MQ], qt * 16, 1, lane), kf1, s, 0, 0, 0); \
                             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(gimg[MQ], qt * 16, 0, lane), vf0, dp, 0, 0, 0); \
                             dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(gimg[MQ], qt * 16, 1, lane), vf1, dp, 0, 0, 0); \
+                            /* dropout words: a lane holds one key and needs, for its 4 query rows, word (key & 3) of    */ \
+                            /* philox(key >> 2, row).  The 4 lanes of a quad share key >> 2: lane t evaluates row 4g + t */ \
+                            /* once and the quad exchanges words (one Philox per lane and tile instead of four).          */ \
+                            uint32_t wr[4] = {~0u, ~0u, ~0u, ~0u};                                         \
+                            if (don) {                                                                     \
+                                const uint32_t drow_t = (uint32_t)(((size_t)b * a.nh + h) * Lq + (qt * 16 + 4 * g + (lq & 3))); \
+                                const u32x4 wq = philox4((uint32_t)(key >> 2), drow_t, dc.site, 0u, (uint32_t)seed, (uint32_t)(seed >> 32)); \
+                                wr[0] = quad_word<0>(wq, lq & 3); wr[1] = quad_word<1>(wq, lq & 3);        \
+                                wr[2] = quad_word<2>(wq, lq & 3); wr[3] = quad_word<3>(wq, lq & 3);        \
+                            }                                                                              \
                             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                \
                                 const int qi = qt * 16 + 4 * g + r;                                        \
                                 float p = 0.f, keep = 1.f;                                                 \
                                 if (qi < Lq && kvalid) {                                                   \
                                     p = __expf(s[r] * a.scale + kmask - lse_s[rbase[MQ] + qi]);            \
-                                    if (don) {                                                             \
-                                        const uint32_t drow = (uint32_t)(((size_t)b * a.nh + h) * Lq + qi); \
-                                        const u32x4 w = philox4((uint32_t)(key >> 2), drow, dc.site, 0u, (uint32_t)seed, (uint32_t)(seed >> 32)); \
-                                        keep = (w[key & 3] >= dc.threshold) ? dc.scale : 0.f;              \
-                                    }                                                                      \
+                                    if (don) keep = (wr[r] >= dc.threshold) ? dc.scale : 0.f;              \
                                 }                                                                          \
                                 pd[hh][r] = p * keep;                                                      \
                                 ds[hh][r] = p * (dp[r] * keep - del_s[rbase[MQ] + (qi < PADS[MQ] ? qi : 0)]); \
