@@ -179,6 +179,42 @@ def write_hf_remap(BertConfig, Model):
         print(tag, len(loaded), "loaded,", len(info["missing_keys"]), "missing,", len(info["unexpected_keys"]), "unexpected", os.path.getsize(path) // 1024, "KB")
 
 
+TASK_CFG = {"TASK1": {"type": "VL-classifier", "num_labels": 37}, "TASK9": {"type": "V-logit"}, "TASK10": {"type": "V-logit", "num_clf_layers": 2},
+            "TASK12": {"type": "VL-binary-classifier"}, "TASK13": {"type": "VL-tri-classifier"}, "TASK8": {"type": "VL-logit"}}
+
+
+def write_tasks(BertConfig):
+    """BertForVLTasks of the real reference (volta/encoders.py:1117-1206) on two tiny configs, every head type, eval mode:
+    predictions and the gradients of a few parameters for loss = sum(prediction * probe)."""
+    import json
+    from volta.encoders import BertForVLTasks
+    for name in ("tiny_vilbert", "tiny_uniter"):
+        cd = dict(tiny_configs()[name], clf_hidden_size=96)
+        cfg = R.RefConfig(cd)
+        ids = list(TASK_CFG)
+        sd = R.make_task_weights(cfg, TASK_CFG, ids, seed=13)
+        batch = R.synthetic_batch(cfg, B=4, T=6, R=4, seed=17, pad=True)
+        model = BertForVLTasks(BertConfig.from_dict(cd), TASK_CFG, ids)
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        blob = {"cfg_json": np.array(json.dumps(cd)), "task_cfg_json": np.array(json.dumps(TASK_CFG)), "ref_keys": np.array(list(model.state_dict().keys()))}
+        for t in ids:
+            model.zero_grad()
+            pred = model(batch["input_ids"], batch["image_feat"].clone(), batch["image_loc"], t, batch["segment_ids"], batch["input_mask"], batch["image_mask"])[0]
+            g = torch.Generator().manual_seed(hash(t) % 1000 if False else sum(map(ord, t)))
+            probe = torch.randn(pred.shape, generator=g)
+            (pred * probe).sum().backward()
+            blob["pred::" + t] = pred.detach().numpy()
+            named = dict(model.named_parameters())
+            for k in ("bert.encoder.layer.0.attention_self.query.weight", "bert.embeddings.word_embeddings.weight", "bert.t_pooler.dense.weight",
+                      "bert.v_pooler.dense.bias", [q for q in named if q.startswith("clfs_dict.%s." % t)][0]):
+                if named[k].grad is not None:
+                    blob["grad::%s::%s" % (t, k)] = named[k].grad.numpy().copy()
+        path = os.path.join(OUT, "tasks_" + name + ".npz")
+        np.savez_compressed(path, **blob)
+        print("tasks", name, {t: blob["pred::" + t].shape for t in ids}, os.path.getsize(path) // 1024, "KB")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -191,3 +227,5 @@ if __name__ == "__main__":
         write_ctrl(BertConfig, Model)
     if which in ("all", "hf"):
         write_hf_remap(BertConfig, Model)
+    if which in ("all", "tasks"):
+        write_tasks(BertConfig)

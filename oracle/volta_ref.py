@@ -735,3 +735,78 @@ def hf_style_bert_state_dict(cfg, n_layers, seed=0, with_prefix=True):
     if with_prefix:
         sd["cls.predictions.decoder.weight"] = sd[pre + "embeddings.word_embeddings.weight"]      # tied in BERT
     return sd
+
+
+# ---------------------------------------------------------------------------------------- downstream tasks
+def task_head_shapes(cfg, task_cfg, task_ids):
+    """Parameter names / shapes of BertForVLTasks.clfs_dict (volta/encoders.py:1128-1152, SimpleClassifier :787-797)."""
+    P, Hc, Hv = cfg.pooler_size, cfg.clf_hidden_size, cfg.v_hidden_size
+    out = {}
+    for t in task_ids:
+        typ, pre = task_cfg[t]["type"], "clfs_dict.%s." % t
+        if typ in ("VL-classifier", "VL-classifier-GQA", "VL-binary-classifier"):
+            din = P * 2 if typ == "VL-binary-classifier" else P
+            dout = 2 if typ == "VL-binary-classifier" else task_cfg[t]["num_labels"]
+            out.update({pre + "logit_fc.0.weight": (Hc, din), pre + "logit_fc.0.bias": (Hc,), pre + "logit_fc.2.weight": (Hc,),
+                        pre + "logit_fc.2.bias": (Hc,), pre + "logit_fc.3.weight": (dout, Hc), pre + "logit_fc.3.bias": (dout,)})
+        elif typ == "VL-tri-classifier":
+            out.update({pre + "weight": (3, P), pre + "bias": (3,)})
+        elif typ == "VL-logit":
+            out.update({pre + "weight": (1, P), pre + "bias": (1,)})
+        elif typ.startswith("V-logit"):
+            if task_cfg[t].get("num_clf_layers", 1) == 2:
+                out.update({pre + "0.weight": (Hv, Hv), pre + "0.bias": (Hv,), pre + "3.weight": (1, Hv), pre + "3.bias": (1,)})
+            else:
+                out.update({pre + "weight": (1, Hv), pre + "bias": (1,)})
+        else:
+            raise ValueError(typ)
+    return out
+
+
+def make_task_weights(cfg, task_cfg, task_ids, seed=0, std=0.05):
+    """Encoder weights of make_weights (without the pre-training heads `cls.*`) + generated task heads."""
+    sd = {k: v for k, v in make_weights(cfg, seed=seed, std=std).items() if not k.startswith("cls.")}
+    for i, (name, shape) in enumerate(task_head_shapes(cfg, task_cfg, task_ids).items()):
+        g = torch.Generator().manual_seed(seed * 100003 + 50000 + i)
+        if name.endswith("logit_fc.2.weight"):
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif len(shape) == 1:
+            t = (std / 2) * torch.randn(shape, generator=g)
+        else:
+            t = std * torch.randn(shape, generator=g)
+        sd[name] = t
+    return sd
+
+
+def tasks_forward(sd, cfg, task_cfg, task_id, input_ids, image_feat, image_loc, token_type_ids=None, attention_mask=None,
+                  image_attention_mask=None, taps=None):
+    """BertForVLTasks.forward in eval mode (volta/encoders.py:1159-1206): vil_prediction."""
+    seq_t, seq_v, pooled_t, pooled_v = bert_model(sd, cfg, input_ids, image_feat, image_loc, token_type_ids, attention_mask,
+                                                   image_attention_mask, taps=taps)
+    if cfg.fusion_method == "mul":
+        pooled = pooled_t * pooled_v
+    elif cfg.fusion_method == "sum":
+        pooled = pooled_t + pooled_v
+    else:
+        raise ValueError(cfg.fusion_method)
+    typ, pre = task_cfg[task_id]["type"], "clfs_dict.%s." % task_id
+
+    def simple(x):
+        h = x @ sd[pre + "logit_fc.0.weight"].t() + sd[pre + "logit_fc.0.bias"]
+        h = layer_norm(gelu(h), sd[pre + "logit_fc.2.weight"], sd[pre + "logit_fc.2.bias"])
+        return h @ sd[pre + "logit_fc.3.weight"].t() + sd[pre + "logit_fc.3.bias"]
+
+    if typ.startswith("V-logit"):
+        if image_attention_mask is None:
+            image_attention_mask = torch.ones(image_feat.shape[:2], dtype=torch.long)
+        if task_cfg[task_id].get("num_clf_layers", 1) == 2:
+            h = gelu(seq_v @ sd[pre + "0.weight"].t() + sd[pre + "0.bias"])
+            out = h @ sd[pre + "3.weight"].t() + sd[pre + "3.bias"]
+        else:
+            out = seq_v @ sd[pre + "weight"].t() + sd[pre + "bias"]
+        return out + ((1.0 - image_attention_mask.float()) * -10000.0).unsqueeze(2)
+    if typ == "VL-binary-classifier":
+        return simple(pooled.view(-1, pooled.size(1) * 2))
+    if typ in ("VL-classifier", "VL-classifier-GQA"):
+        return simple(pooled)
+    return pooled @ sd[pre + "weight"].t() + sd[pre + "bias"]

@@ -179,8 +179,11 @@ class Stream:
 class StepEngine:
     """Buffers + forward / backward command lists of one (B, T, Rv, train) shape."""
 
-    def __init__(self, cfg, arena, B, T, Rv, train):
+    def __init__(self, cfg, arena, B, T, Rv, train, heads="pretrain"):
+        """heads: "pretrain" = the three pre-training heads and losses (BertForVLPreTraining); "tasks" = poolers only, the
+        sequence and pooled outputs leave the engine and their gradients enter it (BertForVLTasks)."""
         self.cfg, self.arena, self.B, self.T, self.Rv, self.train = cfg, arena, B, T, Rv, train
+        self.heads = heads
         dev = arena.device
         self.dev = dev
         H, Hv = cfg.hidden_size, cfg.v_hidden_size
@@ -192,7 +195,7 @@ class StepEngine:
             raise NotImplementedError("per-sub-layer sizes (non-ctrl configs) are out of scope (SURVEY.md 8f-4)")
         if cfg.hidden_act != "gelu" or cfg.v_hidden_act != "gelu" or cfg.fusion_method != "mul":
             raise NotImplementedError("engine supports gelu activations and 'mul' fusion (all ctrl_* configs)")
-        if [k for k, w in cfg.visual_target_weights.items() if w > 0] != ["0"]:
+        if heads == "pretrain" and [k for k, w in cfg.visual_target_weights.items() if w > 0] != ["0"]:
             raise NotImplementedError("only visual target '0' (kl_1601) is on the hot path (SURVEY.md 2.1 #4)")
         if T > 64 or Rv > 128:
             raise NotImplementedError("sequence lengths above (64, 128) exceed the attention tile budget")
@@ -332,7 +335,7 @@ class StepEngine:
                 ops.insert(0, (L.OP_WAIT_SIDE, (k + 2) % 8, 0, 0, None, None, None))
             bwd_stages.append(ops)
             self.taps["t%d" % n], self.taps["v%d" % n] = self.x[0], self.x[1]
-        head_bwd = self._heads()
+        head_bwd = self._heads() if self.heads == "pretrain" else self._heads_tasks()
         # backward list: zero-fills, heads, then stages in reverse; bwd_marks[s] = op index at which backward
         # stage s is complete (stage 0 = heads), param_ready_stage[name] = stage after which its gradient is final
         self.bwd.ops = list(self.bwd_pro) + list(head_bwd)
@@ -341,7 +344,7 @@ class StepEngine:
             self.bwd.ops += ops
             self.bwd_marks.append(len(self.bwd.ops))
         self.bwd.ops.append((L.OP_JOIN, 0, 0, 0, None, None, None))
-        prefixes = [["bert.t_pooler.", "bert.v_pooler.", "cls."]] + [pf for pf in reversed(self.stage_prefix)]
+        prefixes = [["bert.t_pooler.", "bert.v_pooler.", "cls.", "clfs_dict."]] + [pf for pf in reversed(self.stage_prefix)]
         self.param_ready_stage = {}
         for name in self.arena.params:
             self.param_ready_stage[name] = max(i for i, pf in enumerate(prefixes) if any(name.startswith(q) for q in pf))
@@ -993,6 +996,35 @@ class StepEngine:
         dyt, dyv = self.buf("d_pool_t", (B, P)), self.buf("d_pool_v", (B, P))
         b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_POOL_BWD, p=(dpooled, pt, pv, dyt, dyv), n=(B, P, P), drop=pdrop), None, None))
         for m, (dy_, xm, Lm, pre) in enumerate(((dyt, x_t, T, "bert.t_pooler.dense."), (dyv, x_v, Rv, "bert.v_pooler.dense."))):
+            self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dy_, self.W(pre + "weight"), dxh[m], B, H, P, P, H, Lm * H, R=dxh[m], ldr=Lm * H)])
+            self.gemm(b, L.TN, L.EPI_F32, [self.prob(dy_, xm, self.G(pre + "weight"), P, H, B, P, Lm * H, H, bias_grad=self.G(pre + "bias"))])
+        return b
+
+    def _heads_tasks(self):
+        """Poolers only (volta/encoders.py:1004-1011): outputs seq_t, seq_v, pooled_t, pooled_v; the backward is seeded by
+        their upstream gradients, which the host writes (bf16) into `d_seq[m]` (= the dX buffers) and `d_pool_*`."""
+        cfg, B, H, T, Rv = self.cfg, self.B, self.H, self.T, self.Rv
+        f = self.fwd.ops
+        P = cfg.pooler_size
+        if P != cfg.v_pooler_size or P % 64:
+            raise NotImplementedError("pooler sizes must match and be multiples of 64")
+        x_t, x_v = self.x
+        pt, pv = self.buf("pooled_t", (B, P)), self.buf("pooled_v", (B, P))
+        self.gemm(f, L.NT, L.EPI_RELU, [self.prob(x_t, self.W("bert.t_pooler.dense.weight"), pt, B, P, H, T * H, H, P, bias=self.Pm("bert.t_pooler.dense.bias")),
+                                        self.prob(x_v, self.W("bert.v_pooler.dense.weight"), pv, B, P, H, Rv * H, H, P, bias=self.Pm("bert.v_pooler.dense.bias"))])
+        self.taps.update(seq_t=x_t, seq_v=x_v, pooled_t=pt, pooled_v=pv)
+        # The word-embedding gradient is accumulated with atomics by the embedding backward; in the pre-training model the LM
+        # decoder's weight gradient (same tied tensor) is what initialises it, here nothing else writes it: zero it per step.
+        for nm in self.arena.params:
+            if nm.endswith("embeddings.word_embeddings.weight"):
+                self._zero_grad(self.G(nm))
+        b = []
+        dxh = [self._dx(m, self.level[m] % 2) for m in range(2)]
+        self.d_seq = dxh                                   # host copies d(seq_t), d(seq_v) here before the backward list runs
+        self.d_pool = [self.buf("d_pool_t", (B, P)), self.buf("d_pool_v", (B, P))]
+        for m, (xm, Lm, pre, py) in enumerate(((x_t, T, "bert.t_pooler.dense.", pt), (x_v, Rv, "bert.v_pooler.dense.", pv))):
+            dy_ = self.buf("d_pool_pre%d" % m, (B, P))
+            b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_RELU_BWD, p=(self.d_pool[m], py, dy_), n=(B * P,)), None, None))
             self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dy_, self.W(pre + "weight"), dxh[m], B, H, P, P, H, Lm * H, R=dxh[m], ldr=Lm * H)])
             self.gemm(b, L.TN, L.EPI_F32, [self.prob(dy_, xm, self.G(pre + "weight"), P, H, B, P, Lm * H, H, bias_grad=self.G(pre + "bias"))])
         return b

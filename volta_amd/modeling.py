@@ -288,7 +288,7 @@ class BertForVLPreTraining(PreTrainedModel):
         if eng is None:
             for k in [k for k in self._engines if k[3] == key[3]]:      # one plan per mode keeps memory bounded
                 del self._engines[k]
-            eng = StepEngine(self.config, arena, B, T, Rv, train)
+            eng = StepEngine(self.config, arena, B, T, Rv, train, heads=getattr(self, "_heads_mode", "pretrain"))
             self._engines[key] = eng
         return eng
 
@@ -333,22 +333,38 @@ class BertForVLPreTraining(PreTrainedModel):
         self.__dict__["_step"] += 1
         eng.fwd.run()
         self.__dict__["_last"] = (eng, tensors)      # keeps the step's input tensors alive until backward
-        return eng.losses
+        return getattr(eng, "losses", None)
 
     def _engine_backward(self, g_lm, g_img, g_nsp):
         eng, tensors = self._last
+        state = self._backward_begin(eng)
+        eng.gout.copy_(torch.cat([g_lm.reshape(1), g_img.reshape(1), g_nsp.reshape(1)]).to(eng.gout))
+        self._backward_run(eng, state)
+
+    def _backward_begin(self, eng):
+        """Gradient-accumulation bookkeeping shared by the pre-training and the task models.  Parameters of torch-side head
+        modules (`_torch_param_prefixes`) get their gradients from autograd (redirected into the arena by a hook)."""
         arena = eng.arena
-        params = arena.param_list()                   # cached [(name, parameter)]
-        gviews = arena.grad_views()                   # cached views of the gradient arena, one per parameter
+        skip = getattr(self, "_torch_param_prefixes", ())
+        params = [(n, p) for n, p in arena.param_list() if not n.startswith(skip)] if skip else arena.param_list()
+        gviews = [g for (n, _), g in zip(arena.param_list(), arena.grad_views()) if not n.startswith(skip)] if skip else arena.grad_views()
         n_have = sum(p.grad is not None for _, p in params)
         accumulate = n_have == len(params)
         if n_have and not accumulate:
             raise RuntimeError("volta_amd: some parameters carry a .grad and some do not; zero_grad() all of them")
+        old = None
         if accumulate:
             if not all(p.grad is g or p.grad.data_ptr() == g.data_ptr() for (_, p), g in zip(params, gviews)):
                 raise RuntimeError("volta_amd: .grad tensors were replaced by foreign tensors; call zero_grad(set_to_none=True)")
             old = arena.grad.clone()
-        eng.gout.copy_(torch.cat([g_lm.reshape(1), g_img.reshape(1), g_nsp.reshape(1)]).to(eng.gout))
+        return params, gviews, accumulate, old
+
+    def _backward_run(self, eng, state):
+        params, gviews, accumulate, old = state
+        arena = eng.arena
+        skip = getattr(self, "_torch_param_prefixes", ())
+        if skip:            # the engine list zero-fills / overwrites only what it owns; torch-side head gradients are already in the arena
+            keep = [(g, g.clone()) for (n, _), g in zip(arena.param_list(), arena.grad_views()) if n.startswith(skip)] if accumulate else []
         ddp = self.__dict__.get("_ddp")
         if ddp is not None:
             ddp.run_backward(eng)
@@ -357,6 +373,9 @@ class BertForVLPreTraining(PreTrainedModel):
         if accumulate:
             from . import _lib as L
             L.check(L.lib.vk_axpy_f32(L.ptr(arena.grad), L.ptr(old), 1.0, arena.total, L.stream_ptr()))
+            if skip:
+                for g, saved in keep:
+                    g.copy_(saved)
         else:
             for (_, p), g in zip(params, gviews):
                 p.grad = g
@@ -395,3 +414,167 @@ class BertForVLPreTraining(PreTrainedModel):
         H = self.config.hidden_size
         return (eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, H).float(),
                 eng.taps["pooled_t"].float(), eng.taps["pooled_v"].float(), ([], []))
+
+
+# ======================================================================================== downstream tasks
+class SimpleClassifier(nn.Module):
+    """Linear -> GELU -> LayerNorm -> Linear (volta/encoders.py:787-815).  A few MFLOP on [B, pooler_size]: stock torch modules."""
+
+    def __init__(self, in_dim, hid_dim, out_dim, dropout_prob=0.0):
+        super().__init__()
+        self.logit_fc = nn.Sequential(nn.Linear(in_dim, hid_dim), nn.GELU(), nn.LayerNorm(hid_dim, eps=1e-12), nn.Linear(hid_dim, out_dim))
+
+    def forward(self, hidden_states):
+        return self.logit_fc(hidden_states)
+
+
+class _TaskEncode(torch.autograd.Function):
+    """Encoder + poolers as one autograd node: the four outputs leave the engine as fp32 tensors, their gradients re-enter it."""
+
+    @staticmethod
+    def forward(ctx, model, anchor, tensors):
+        model._engine_forward(tensors)
+        eng = model._last[0]
+        ctx.model = model
+        B, T = tensors["input_ids"].shape
+        Rv = tensors["image_feat"].shape[1]
+        H = model.config.hidden_size
+        return (eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, H).float(),
+                eng.taps["pooled_t"].float(), eng.taps["pooled_v"].float())
+
+    @staticmethod
+    def backward(ctx, g_seq_t, g_seq_v, g_pt, g_pv):
+        model = ctx.model
+        eng, _ = model._last
+        state = model._backward_begin(eng)
+        for dst, g in ((eng.d_seq[0], g_seq_t), (eng.d_seq[1], g_seq_v), (eng.d_pool[0], g_pt), (eng.d_pool[1], g_pv)):
+            if g is None:
+                dst.zero_()
+            else:
+                dst.copy_(g.reshape(dst.shape))
+        model._backward_run(eng, state)
+        return None, None, None
+
+
+class BertForVLTasks(PreTrainedModel):
+    """Fine-tuning / evaluation model of the downstream tasks (volta/encoders.py:1117-1206): the gated encoder runs on the HIP
+    engine (forward AND backward), the small task heads are torch modules on its pooled / region outputs."""
+
+    _heads_mode = "tasks"
+    _torch_param_prefixes = ("clfs_dict.",)
+    _vk_is_model = True
+    materialize = BertForVLPreTraining.materialize
+    _engine = BertForVLPreTraining._engine
+    _prep_inputs = BertForVLPreTraining._prep_inputs
+    _engine_forward = BertForVLPreTraining._engine_forward
+    _backward_begin = BertForVLPreTraining._backward_begin
+    _backward_run = BertForVLPreTraining._backward_run
+    set_dropout_seed = BertForVLPreTraining.set_dropout_seed
+
+    def __init__(self, config, task_cfg, task_ids, dropout_prob=0.1):
+        super().__init__(config)
+        self.bert = BertModel(config)
+        self.dropout = nn.Dropout(dropout_prob)
+        self.task_cfg = task_cfg
+        task2clf = {}
+        for task_id in task_ids:
+            task_type = task_cfg[task_id]["type"]
+            if task_type in {"VL-classifier", "VL-classifier-GQA"}:
+                task2clf[task_id] = SimpleClassifier(config.pooler_size, config.clf_hidden_size, task_cfg[task_id]["num_labels"])
+            elif task_type == "VL-binary-classifier":
+                task2clf[task_id] = SimpleClassifier(config.pooler_size * 2, config.clf_hidden_size, 2)
+            elif task_type == "VL-tri-classifier":
+                task2clf[task_id] = nn.Linear(config.pooler_size, 3)
+            elif task_type == "VL-logit":
+                task2clf[task_id] = nn.Linear(config.pooler_size, 1)
+            elif task_type.startswith("V-logit"):
+                if task_cfg[task_id].get("num_clf_layers", 1) == 2:
+                    task2clf[task_id] = nn.Sequential(nn.Linear(config.v_hidden_size, config.v_hidden_size), nn.GELU(),
+                                                      nn.Dropout(config.v_attention_probs_dropout_prob, inplace=False),
+                                                      nn.Linear(config.v_hidden_size, 1))
+                else:
+                    task2clf[task_id] = nn.Linear(config.v_hidden_size, 1)
+            else:
+                raise ValueError("Undefined task type: %s" % task_type)
+        self.clfs_dict = nn.ModuleDict(task2clf)
+        self.fusion_method = config.fusion_method
+        for mod in self.clfs_dict.modules():                     # the outer apply(init_weights) of the reference (utils.py:377-389)
+            if isinstance(mod, nn.Linear):
+                mod.weight.data.normal_(mean=0.0, std=config.initializer_range)
+                if mod.bias is not None:
+                    mod.bias.data.zero_()
+            elif isinstance(mod, nn.LayerNorm):
+                mod.bias.data.zero_()
+                mod.weight.data.fill_(1.0)
+        self.add_global_imgfeat = int(config.add_global_imgfeat is not None)
+        self.__dict__["_arena"] = None
+        self.__dict__["_engines"] = {}
+        self.__dict__["_step"] = 0
+        self.__dict__["_seed_base"] = None
+        self.__dict__["_last"] = None
+        self.__dict__["_ddp"] = None
+        self.bert.__dict__["_root"] = self
+        for mod in self.modules():
+            if mod is not self and isinstance(mod, PreTrainedModel):
+                mod.__dict__["_root"] = self
+        for n, p in self.named_parameters():
+            p._vk_owner = self
+            if n.startswith(self._torch_param_prefixes):
+                p.register_post_accumulate_grad_hook(self._redirect_head_grad)
+
+    def _redirect_head_grad(self, p):
+        """Gradients of the torch-side heads live in the flat gradient arena like every other one (clip / AdamW walk the arena)."""
+        arena = self.__dict__.get("_arena")
+        if arena is None or p.grad is None:
+            return
+        idx = self.__dict__.get("_head_index")
+        if idx is None or idx[0] is not arena:
+            idx = (arena, {id(q): g for (_, q), g in zip(arena.param_list(), arena.grad_views())})
+            self.__dict__["_head_index"] = idx
+        gv = idx[1][id(p)]
+        if p.grad is not gv:
+            gv.copy_(p.grad)
+            p.grad = gv
+
+    def encode(self, input_ids, image_feat, image_loc, token_type_ids=None, attention_mask=None, image_attention_mask=None):
+        """BertModel.forward under no_grad (BertModel.forward delegates here)."""
+        tensors, B, T, Rv = self._prep_inputs(input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask,
+                                              None, None, None, None)
+        with torch.no_grad():
+            self._engine_forward(tensors)
+        eng = self._last[0]
+        H = self.config.hidden_size
+        return (eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, H).float(),
+                eng.taps["pooled_t"].float(), eng.taps["pooled_v"].float(), ([], []))
+
+    def forward(self, input_txt, input_imgs, image_loc, task_id, token_type_ids=None, attention_mask=None,
+                image_attention_mask=None, output_all_encoded_layers=False, output_all_attention_masks=False):
+        if output_all_encoded_layers or output_all_attention_masks:
+            raise NotImplementedError("intermediate layer / attention-map outputs are not materialised by the fused engine")
+        tensors, B, T, Rv = self._prep_inputs(input_txt, input_imgs, image_loc, token_type_ids, attention_mask, image_attention_mask,
+                                              None, None, None, None)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.bert.parameters()):
+            self.materialize()
+            anchor = next(p for p in self.bert.parameters() if p.requires_grad)
+            seq_t, seq_v, pooled_t, pooled_v = _TaskEncode.apply(self, anchor, tensors)
+        else:
+            self.materialize()
+            with torch.no_grad():
+                self._engine_forward(tensors)
+            eng = self._last[0]
+            H = self.config.hidden_size
+            seq_t, seq_v = eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, H).float()
+            pooled_t, pooled_v = eng.taps["pooled_t"].float(), eng.taps["pooled_v"].float()
+        if self.fusion_method == "mul":
+            pooled_output = self.dropout(pooled_t * pooled_v)
+        else:
+            raise ValueError("Invalid fusion method: %s" % self.fusion_method)
+        task_type = self.task_cfg[task_id]["type"]
+        if task_type.startswith("V-logit"):
+            mask = tensors["image_attention_mask"].to(seq_v.dtype)
+            vil_prediction = self.clfs_dict[task_id](self.dropout(seq_v)) + ((1.0 - mask) * -10000.0).unsqueeze(2)
+        elif task_type == "VL-binary-classifier":
+            vil_prediction = self.clfs_dict[task_id](pooled_output.view(-1, pooled_output.size(1) * 2))
+        else:
+            vil_prediction = self.clfs_dict[task_id](pooled_output)
+        return vil_prediction, None, None, ([], [])
