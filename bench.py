@@ -120,9 +120,17 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU path")
+    # VK_BENCH_SHARED_GPU=1 is a REHEARSAL mode for the multi-rank code path on a one-GPU box: every rank uses cuda:0 and the
+    # collectives go through gloo (RCCL refuses two ranks on one device); its timings mean nothing and the output says so.
+    shared = os.environ.get("VK_BENCH_SHARED_GPU") == "1"
+    if shared:
+        local = 0
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     from volta_amd.config import BertConfig
     from volta_amd.modeling import BertForVLPreTraining
     from volta_amd.optimization import AdamW, WarmupLinearSchedule, clip_grad_norm_
@@ -185,7 +193,8 @@ def main():
                       % (a.config, "+allreduce" if world > 1 else "", a.batch, a.seq_len, a.regions),
                       "global_batch": a.batch * world, "seq_len": a.seq_len, "regions": a.regions, "parallelism": "dp%d" % world},
            "host_issue_ms_per_step": t_issue * 1e3 / a.steps,
-           "losses_last_step": [float(x) for x in losses]}
+           **({"rehearsal": "all ranks share cuda:0 over gloo: timings are meaningless"} if shared else {}),
+           "losses_last_step": [float(x.detach()) for x in losses]}
     if rank == 0:
         print("[bench] timed region done: %.3f ms/step, %.1f pairs/s" % (ms, pairs_s), file=sys.stderr, flush=True)
         if gflop is not None:
