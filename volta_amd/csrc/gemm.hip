@@ -219,6 +219,7 @@ static int launch_cfg(int epi, const KGroup& g, int total, hipStream_t s) {
 
 static int g_tile_override = 0;       // tuning hook: 0 = heuristic, 128 / 256 / 257 = force 128x128 / 256x256 8-phase / legacy 256x256
 static int g_stagger = 1;
+static int g_min_tiles256_tn = 50;   // TN (weight gradients, side stream): fewer, longer workgroups leave more CUs to the critical path (19.71 -> 19.54 ms)
 static int g_min_tiles256 = 160;   // fewest 256 x 256 tiles for which that geometry is chosen (256 CUs)
 static int g_debug = 0;            // ablation switches of the 256 x 256 kernel (gemm256.hip)
 static int g_regstage_override = -1;  // -1 = heuristic, 0 / 1 = force LDS-DMA / register staging (128^2 only)
@@ -256,6 +257,7 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
     // Tuning hook values: 128, 256, 257 (= the legacy 16-wave 256 x 256 kernel, kept for A/B runs).
     static const bool env_once = [] {       // tuning overrides from the environment (tools only; unset in production)
         if (const char* e = getenv("VK_GEMM_MIN_TILES256")) g_min_tiles256 = atoi(e);
+        if (const char* e = getenv("VK_GEMM_MIN_TILES256_TN")) g_min_tiles256_tn = atoi(e);
         if (const char* e = getenv("VK_GEMM_TILE")) g_tile_override = atoi(e);
         return true;
     }();
@@ -268,7 +270,7 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
     int edge = g_tile_override;
     if (edge == 0) {
         const int t256 = total_tiles(probs, nprob, epilogue, 256, 256), t192 = total_tiles(probs, nprob, epilogue, 256, 192);
-        if (t256 < g_min_tiles256) edge = 128;
+        if (t256 < (layout == VK_TN ? g_min_tiles256_tn : g_min_tiles256)) edge = 128;
         else {
             const double c256 = (double)((t256 + 255) / 256) * 256.0, c192 = (double)((t192 + 255) / 256) * 192.0;
             edge = c192 < 0.97 * c256 ? 259 : 258;
