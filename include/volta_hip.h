@@ -363,6 +363,37 @@ int vk_side_join(vk_stream_t s);
 /* 0: run side-stream blocks inline on the caller's stream (serial schedule); 1 (default): concurrently. */
 void vk_side_enable(int on);
 
+/* ------------------------------------------------------------------------------------------------
+ * ConceptCap batch producer: raw records -> the model's input tensors with the reference's sampling policy.
+ * Replaces BertPreprocessBatch.__call__ / convert_example_to_features / random_word / random_region / iou and the global-feature
+ * code of ConceptCapLoaderTrain.__iter__ (volta/datasets/concept_cap_dataset.py:31-68, 229-286, 429-668) plus the objective-1
+ * relabel of train_concap.py:279-284.  Decisions are words of Philox streams of `seed` (see csrc/concap.hip). */
+typedef struct vk_concap_args {
+    const int32_t* cap_tokens;   /* [n_caps, cap_ld] caption token ids without [CLS] / [SEP]            */
+    const int32_t* cap_len;      /* [n_caps]                                                            */
+    const int32_t* cap_index;    /* [B] caption of each pair                                            */
+    const float* feat;           /* [B, R, F] region features (rows >= num_boxes are ignored)           */
+    const float* cls;            /* [B, R, C] class distributions                                       */
+    const float* boxes;          /* [B, R, 4] x1, y1, x2, y2 in pixels                                  */
+    const int32_t* num_boxes;    /* [B]                                                                 */
+    const float* img_wh;         /* [B, 2] image width, height                                          */
+    int64_t* input_ids;          /* [B, T]                                                              */
+    int64_t* input_mask;         /* [B, T]                                                              */
+    int64_t* segment_ids;        /* [B, T]                                                              */
+    int64_t* lm_label_ids;       /* [B, T]                                                              */
+    int64_t* is_match;           /* [B]  1 = caption replaced                                           */
+    float* image_feat;           /* [B, R + (add_global != 0), F]                                       */
+    float* image_loc;            /* [B, R + (add_global != 0), 5]                                       */
+    float* image_cls;            /* [B, R, C]                                                           */
+    int64_t* image_label;        /* [B, R]                                                              */
+    int64_t* image_mask;         /* [B, R + (add_global != 0)]                                          */
+    uint64_t seed;
+    int32_t B, T, R, F, C, n_caps, cap_ld, vocab_size, cls_id, sep_id, mask_id;
+    int32_t add_global;          /* 0 none, 1 first, 2 last                                             */
+    int32_t objective;           /* 0, 1 (mismatched pairs lose their MLM / region labels), 2 (no swaps) */
+} vk_concap_args;
+int vk_concap_batch(const vk_concap_args* a, vk_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

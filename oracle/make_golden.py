@@ -215,6 +215,101 @@ def write_tasks(BertConfig):
         print("tasks", name, {t: blob["pred::" + t].shape for t in ids}, os.path.getsize(path) // 1024, "KB")
 
 
+def concap_records(n_pairs, region_len, seed, F=2048, C=1601, ragged=False):
+    """Raw per-pair records (what the LMDB rows hold, concept_cap_dataset.py:430-431) from a seed: shared with the tests."""
+    rng = np.random.default_rng(seed)
+    recs = []
+    for b in range(n_pairs):
+        # the reference only works with num_boxes == region_len (its `masked_label` / `overlaps` shapes, :645-659, differ otherwise)
+        n = int(rng.integers(3, region_len + 1)) if ragged else region_len
+        w, h = float(rng.integers(300, 800)), float(rng.integers(300, 800))
+        xy = rng.uniform(0, 0.6, (n, 2)) * np.array([w, h])
+        wh = rng.uniform(0.1, 0.4, (n, 2)) * np.array([w, h])
+        boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        if n > 3:
+            boxes[1] = boxes[0] + rng.uniform(-4, 4, 4).astype(np.float32)          # a heavily overlapping pair (IoU > 0.4)
+        cls = rng.random((n, C), dtype=np.float32)
+        recs.append(dict(caption_index=b, feat=rng.random((n, F), dtype=np.float32), cls=cls / cls.sum(1, keepdims=True), boxes=boxes, w=w, h=h))
+    caps = [[int(t) for t in rng.integers(1000, 3000, int(rng.integers(2, 16)))] for _ in range(n_pairs + 5)]
+    return recs, caps
+
+
+def write_concap():
+    """The REAL BertPreprocessBatch.__call__ and ConceptCapLoaderTrain.__iter__ (volta/datasets/concept_cap_dataset.py) on synthetic raw
+    records, with their random draws replaced by the producer's word streams (oracle/volta_ref.py:concap_words): pins the oracle's
+    restatement of the masking policy, the box normalisation, IoU co-masking and the global-feature row.  The module is loaded by file
+    path with empty stand-ins for `tensorpack` / `msgpack_numpy` (LMDB plumbing the called code never touches)."""
+    import importlib.util, random as pyrandom
+    for name in ("tensorpack", "tensorpack.dataflow", "msgpack_numpy"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["tensorpack"].dataflow = sys.modules["tensorpack.dataflow"]
+    sys.modules["msgpack_numpy"].patch = lambda: None
+    spec = importlib.util.spec_from_file_location("ref_concap", os.path.join(REF, "volta", "datasets", "concept_cap_dataset.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    T, Rl, V, seed, B = 14, 10, 3000, 77, 8
+    recs, caps = concap_records(B, Rl, seed=3)
+    w_tok, w_rnd = R.concap_words(seed, R.CC_SITE_TOKEN, B, T), R.concap_words(seed, R.CC_SITE_RANDTOK, B, T)
+    w_reg, w_cap = R.concap_words(seed, R.CC_SITE_REGION, B, Rl), R.concap_words(seed, R.CC_SITE_CAPTION, B, 2)
+
+    class Tok:
+        mask_token = "[MASK]"
+        def encode(self, caption): return list(caption)
+        def add_special_tokens_single_sentence(self, tokens): return [101] + list(tokens) + [102]
+        def convert_tokens_to_ids(self, tok): return 103
+        def __len__(self): return V
+
+    class Draws:      # stands in for the `random` module inside the reference file: replays the word streams in call order
+        def __init__(self, b): self.b, self.k = b, 0
+        def random(self):
+            k, self.k = self.k, self.k + 1
+            if k == 0:
+                return float(w_cap[self.b, 0]) / 2.0 ** 32
+            ntok = self.ntok
+            return float(w_tok[self.b, k - 1]) / 2.0 ** 32 if k - 1 < ntok else float(w_reg[self.b, k - 1 - ntok]) / 2.0 ** 32
+        def randint(self, lo, hi):
+            return int(w_cap[self.b, 1]) % (hi - lo + 1) + lo
+
+    proc = object.__new__(mod.BertPreprocessBatch)
+    proc.split, proc.seq_len, proc.region_len, proc.tokenizer, proc.num_caps = "Train", T, Rl, Tok(), len(caps)
+    proc.captions, proc.visualization, proc.objective, proc.bert_model, proc.num_locs = caps, False, 0, "bert-base-uncased", 5
+    rows = []
+    real_randint = np.random.randint
+    for b, rec in enumerate(recs):
+        n = rec["feat"].shape[0]
+        d = Draws(b)
+        swapped = float(w_cap[b, 0]) / 2.0 ** 32 > 0.5
+        d.ntok = min(len(caps[int(w_cap[b, 1]) % len(caps)] if swapped else caps[rec["caption_index"]]), T - 2)
+        mod.random = d
+        np.random.randint = lambda hi, _d=d: int(w_rnd[_d.b, _d.k - 2]) % hi        # token index of the draw just made
+        try:
+            data = (rec["feat"], rec["cls"], np.zeros(n, np.int64), np.zeros(n, np.float32), np.zeros(n, np.int64), np.zeros(n, np.float32),
+                    np.zeros((n, 401), np.float32), rec["boxes"].copy(), n, rec["h"], rec["w"], b, caps[rec["caption_index"]])
+            rows.append(proc(data))
+        finally:
+            np.random.randint = real_randint
+    mod.random = pyrandom
+    batch = [np.stack([np.asarray(r[i]) for r in rows]) for i in range(17)]
+    loader = object.__new__(mod.ConceptCapLoaderTrain)
+    loader.add_global_imgfeat, loader.num_locs = "first", 5
+    loader.ds = types.SimpleNamespace(get_data=lambda: iter([batch]))
+    out = next(iter(loader))
+    names = ["input_ids", "input_mask", "segment_ids", "lm_label_ids", "is_next", "image_feat", "image_loc", "image_cls", "obj_labels", "obj_confs",
+             "attr_labels", "attr_confs", "image_attrs", "image_label", "image_mask"]
+    o = {k: v.numpy() for k, v in zip(names, out[:15])}
+    blob = {"params": np.array([T, Rl, V, seed, B, 3]), "masked_label": batch[15].astype(np.int8)}
+    for k in ("input_ids", "input_mask", "segment_ids", "lm_label_ids", "is_next", "image_loc", "image_label", "image_mask"):
+        blob[k] = o[k]
+    blob["image_feat_rowsum"] = o["image_feat"].astype(np.float64).sum(2)
+    blob["image_feat_global_head"] = o["image_feat"][:, 0, :128]
+    blob["image_cls_rowsum"] = o["image_cls"].astype(np.float64).sum(2)
+    path = os.path.join(OUT, "concap_batch.npz")
+    np.savez_compressed(path, **blob)
+    print("concap", {k: v.shape for k, v in blob.items()}, "swapped", o["is_next"].tolist(), "masked tokens", int((o["lm_label_ids"] != -1).sum()),
+          "masked regions", int((o["image_label"] == 1).sum()), os.path.getsize(path) // 1024, "KB")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -229,3 +324,5 @@ if __name__ == "__main__":
         write_hf_remap(BertConfig, Model)
     if which in ("all", "tasks"):
         write_tasks(BertConfig)
+    if which in ("all", "concap"):
+        write_concap()

@@ -810,3 +810,132 @@ def tasks_forward(sd, cfg, task_cfg, task_id, input_ids, image_feat, image_loc, 
     if typ in ("VL-classifier", "VL-classifier-GQA"):
         return simple(pooled)
     return pooled @ sd[pre + "weight"].t() + sd[pre + "bias"]
+
+
+# ---------------------------------------------------------------------------------------- ConceptCap batch producer
+# The reference draws from Python's `random` / numpy; here every decision is a function of an explicit 32-bit word per
+# (pair, slot, stream) so that the policy can be replayed: the product's HIP kernels take the words from Philox
+# (stream = site, counter = (slot, pair, site, 0)), the fixtures feed the reference code the same words as word / 2^32.
+CC_T15 = int(0.15 * 2 ** 32)            # "prob < 0.15"
+CC_SITE_TOKEN, CC_SITE_RANDTOK, CC_SITE_REGION, CC_SITE_CAPTION = 0, 1, 2, 3
+
+
+def concap_words(seed, site, n_pairs, n_slots):
+    """uint32 [n_pairs, n_slots]: word 0 of philox(counter = (slot, pair, site, 0), key = seed)."""
+    import numpy as np
+    pair = np.repeat(np.arange(n_pairs, dtype=np.uint32), n_slots)
+    slot = np.tile(np.arange(n_slots, dtype=np.uint32), n_pairs)
+    w = philox_raw(slot, pair, np.full_like(pair, site), np.zeros_like(pair), seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+    return w[:, 0].reshape(n_pairs, n_slots)
+
+
+def concap_iou(boxes):
+    """Pairwise IoU with the +1 pixel convention (volta/datasets/concept_cap_dataset.py:31-68); boxes [N, 4] float."""
+    import numpy as np
+    b = np.asarray(boxes, np.float32)
+    area = (b[:, 2] - b[:, 0] + 1) * (b[:, 3] - b[:, 1] + 1)
+    iw = np.minimum(b[:, None, 2], b[None, :, 2]) - np.maximum(b[:, None, 0], b[None, :, 0]) + 1
+    ih = np.minimum(b[:, None, 3], b[None, :, 3]) - np.maximum(b[:, None, 1], b[None, :, 1]) + 1
+    iw, ih = np.maximum(iw, 0), np.maximum(ih, 0)
+    return iw * ih / (area[:, None] + area[None, :] - iw * ih)
+
+
+def concap_random_word(tokens, words, rand_words, vocab_size, mask_id):
+    """random_word (concept_cap_dataset.py:612-641): 15 % of the tokens are selected; of those 80 % -> [MASK], 10 % -> a random
+    id, 10 % kept; the label is the original id, -1 elsewhere.  `prob / 0.15 < 0.8` is evaluated on the same draw."""
+    out, lab = list(tokens), []
+    for i, tok in enumerate(tokens):
+        prob = float(words[i]) / 2.0 ** 32
+        if prob < 0.15:
+            prob /= 0.15
+            if prob < 0.8:
+                out[i] = mask_id
+            elif prob < 0.9:
+                out[i] = int(rand_words[i]) % vocab_size
+            lab.append(tok)
+        else:
+            lab.append(-1)
+    return out, lab
+
+
+def concap_random_region(image_feat, num_boxes, overlaps, words):
+    """random_region (concept_cap_dataset.py:643-668): 15 % of the boxes get label 1, 90 % of those have their feature row
+    zeroed; `masked_label` ORs the IoU > 0.4 rows of every selected box (it only feeds the global-feature count)."""
+    import numpy as np
+    feat = np.array(image_feat, np.float32, copy=True)
+    label, masked = [], np.zeros(feat.shape[0], bool)
+    for i in range(num_boxes):
+        prob = float(words[i]) / 2.0 ** 32
+        if prob < 0.15:
+            prob /= 0.15
+            if prob < 0.9:
+                feat[i] = 0
+            masked = np.logical_or(masked, overlaps[i] > 0.4)
+            label.append(1)
+        else:
+            label.append(-1)
+    return feat, label, masked
+
+
+def concap_make_batch(records, captions, seed, seq_len, region_len, vocab_size, add_global="first", num_locs=5, objective=1,
+                      cls_id=101, sep_id=102, mask_id=103):
+    """BertPreprocessBatch.__call__ + convert_example_to_features + ConceptCapLoaderTrain.__iter__ (concept_cap_dataset.py:
+    429-500, 546-610, 229-286) + the objective-1 relabel of train_concap.py:279-284, on a list of raw records
+    {caption_index, feat [n, F], cls [n, C], boxes [n, 4] (pixels), w, h}.  Returns the dict of the model's input tensors."""
+    import numpy as np
+    B, T, R = len(records), seq_len, region_len
+    F, C = records[0]["feat"].shape[1], records[0]["cls"].shape[1]
+    w_tok = concap_words(seed, CC_SITE_TOKEN, B, T)
+    w_rnd = concap_words(seed, CC_SITE_RANDTOK, B, T)
+    w_reg = concap_words(seed, CC_SITE_REGION, B, R)
+    w_cap = concap_words(seed, CC_SITE_CAPTION, B, 2)
+    out = dict(input_ids=np.zeros((B, T), np.int64), input_mask=np.zeros((B, T), np.int64), segment_ids=np.zeros((B, T), np.int64),
+               lm_label_ids=np.full((B, T), -1, np.int64), is_match=np.zeros(B, np.int64), image_label=np.full((B, R), -1, np.int64),
+               image_cls=np.zeros((B, R, C), np.float32))
+    feats, locs, masks, masked_all = [], [], [], []
+    for b, rec in enumerate(records):
+        n = int(rec["feat"].shape[0])
+        # random_cap (:505-522): objective 2 never swaps
+        cap_idx, label = rec["caption_index"], 0
+        if objective != 2 and float(w_cap[b, 0]) / 2.0 ** 32 > 0.5:
+            cap_idx, label = int(w_cap[b, 1]) % len(captions), 1
+        tokens = list(captions[cap_idx])[:T - 2]
+        tokens, tok_lab = concap_random_word(tokens, w_tok[b], w_rnd[b], vocab_size, mask_id)
+        ids = [cls_id] + tokens + [sep_id]
+        out["input_ids"][b, :len(ids)] = ids
+        out["input_mask"][b, :len(ids)] = 1
+        out["lm_label_ids"][b, 1:1 + len(tok_lab)] = tok_lab
+        out["is_match"][b] = label
+        feat = np.zeros((R, F), np.float32)
+        feat[:n] = rec["feat"]
+        out["image_cls"][b, :n] = rec["cls"]
+        loc = np.zeros((R, num_locs), np.float32)
+        loc[:n, :4] = rec["boxes"]
+        if num_locs == 5:
+            loc[:, 4] = (loc[:, 3] - loc[:, 1]) * (loc[:, 2] - loc[:, 0]) / (float(rec["w"]) * float(rec["h"]))
+        loc[:, 0] /= float(rec["w"]); loc[:, 2] /= float(rec["w"]); loc[:, 1] /= float(rec["h"]); loc[:, 3] /= float(rec["h"])
+        ov = np.zeros((R, R), np.float32)
+        ov[:n, :n] = concap_iou(rec["boxes"])
+        feat, lab, masked = concap_random_region(feat, n, ov, w_reg[b])
+        out["image_label"][b, :n] = lab
+        feats.append(feat); locs.append(loc); masked_all.append(masked)
+        masks.append(np.concatenate([np.ones(n, np.int64), np.zeros(R - n, np.int64)]))
+    feat, loc, mask, masked = np.stack(feats), np.stack(locs), np.stack(masks), np.stack(masked_all)
+    if add_global is not None:
+        cnt = np.sum(masked == 0, axis=1, keepdims=True)
+        cnt[cnt == 0] = 1
+        g = (np.sum(feat, axis=1) / cnt).astype(np.float32)[:, None]
+        gloc = np.tile(np.array([[0, 0, 1, 1] + [1] * (num_locs - 4)], np.float32), (B, 1))[:, None]
+        one = np.ones((B, 1), np.int64)
+        if add_global == "first":
+            feat, loc, mask = np.concatenate([g, feat], 1), np.concatenate([gloc, loc], 1), np.concatenate([one, mask], 1)
+        else:
+            feat, loc, mask = np.concatenate([feat, g], 1), np.concatenate([loc, gloc], 1), np.concatenate([mask, one], 1)
+    out.update(image_feat=feat.astype(np.float32), image_loc=loc.astype(np.float32), image_mask=mask)
+    if objective == 1:      # train_concap.py:279-284: mismatched pairs carry no MLM / region targets
+        keep = (out["is_match"] == 0).astype(np.int64)
+        for k in ("image_label", "lm_label_ids"):
+            v = out[k] * keep[:, None]
+            v[v == 0] = -1
+            out[k] = v
+    return out

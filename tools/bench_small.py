@@ -54,7 +54,26 @@ def attn(gate, T=20, R=37, B=256, nh=12, H=768):
         print("ATTN gate=%s p=%.1f  fwd %6.1f us  bwd %6.1f us" % (gate, p, tf, tb), flush=True)
 
 
+def concap(B=256, T=20, Rl=36, F=2048, Cn=1601):
+    """ConceptCap batch producer at the benchmark shape: bytes = raw features + class distributions read and written once."""
+    from volta_amd.data import ConceptCapBatchProducer
+    g = torch.Generator(device="cuda").manual_seed(0)
+    caps = [[int(x) for x in torch.randint(1000, 30000, (int(n),))] for n in torch.randint(4, 19, (B + 100,))]
+    prod = ConceptCapBatchProducer(caps, T, Rl, 30522)
+    feat = torch.rand(B, Rl, F, device="cuda", generator=g)
+    cls = torch.softmax(torch.randn(B, Rl, Cn, device="cuda", generator=g), -1)
+    xy = torch.rand(B, Rl, 2, device="cuda", generator=g) * 300
+    boxes = torch.cat([xy, xy + 50 + torch.rand(B, Rl, 2, device="cuda", generator=g) * 200], -1)
+    nb = torch.full((B,), Rl, dtype=torch.int32, device="cuda")
+    wh = torch.full((B, 2), 640.0, device="cuda")
+    ci = torch.arange(B, dtype=torch.int32, device="cuda")
+    us = timeit(lambda: prod(feat, cls, boxes, nb, wh, ci, 7), iters=20)
+    by = 2 * 4 * (feat.numel() + cls.numel())
+    print("CONCAP producer B=%d: %.1f us per batch (%.2f TB/s over %.0f MB read+written) = %.1f M pairs/s" % (B, us, by / us / 1e6, by / 1e6, B / us), flush=True)
+
+
 if __name__ == "__main__":
+    concap()
     import ctypes
     ln(5120)
     ln(9472)

@@ -58,6 +58,13 @@ class LnBwdArgs(C.Structure):
                 ("seg", DropRows * 2)]
 
 
+class ConcapArgs(C.Structure):
+    _fields_ = [(n, c_p) for n in ("cap_tokens", "cap_len", "cap_index", "feat", "cls", "boxes", "num_boxes", "img_wh", "input_ids", "input_mask",
+                                   "segment_ids", "lm_label_ids", "is_match", "image_feat", "image_loc", "image_cls", "image_label", "image_mask")] + \
+               [("seed", C.c_uint64)] + [(n, i32) for n in ("B", "T", "R", "F", "C", "n_caps", "cap_ld", "vocab_size", "cls_id", "sep_id", "mask_id",
+                                                            "add_global", "objective")]
+
+
 class EmbedArgs(C.Structure):
     _fields_ = [("ids", c_p), ("type_ids", c_p), ("pos_ids", c_p), ("word", c_p), ("pos", c_p), ("type", c_p),
                 ("extra", c_p), ("z", c_p), ("M", i32), ("T", i32), ("H", i32), ("V", i32), ("P", i32), ("n_types", i32)]
@@ -168,6 +175,7 @@ _sig("vk_run_ops_timed", C.c_int, C.POINTER(Op), C.c_int, c_p, C.POINTER(C.c_flo
 _sig("vk_ln_bwd_finalize", C.c_int, C.POINTER(LnBwdArgs), c_p)
 _sig("vk_ln_fwd_pair", C.c_int, C.POINTER(LnArgs), C.POINTER(LnArgs), c_p)
 _sig("vk_ln_bwd_pair", C.c_int, C.POINTER(LnBwdArgs), C.POINTER(LnBwdArgs), c_p)
+_sig("vk_concap_batch", C.c_int, C.POINTER(ConcapArgs), c_p)
 _sig("vk_side_join", C.c_int, c_p)
 _sig("vk_side_enable", None, C.c_int)
 
@@ -178,7 +186,7 @@ EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_c
            "vk_relu_bwd_bf16", "vk_copy_async", "vk_select_rows", "vk_gather_rows", "vk_scatter_rows_add", "vk_xent_fwd",
            "vk_xent_bwd", "vk_kl_fwd", "vk_kl_bwd", "vk_loss_finalize", "vk_pool_mul_fwd", "vk_pool_mul_bwd",
            "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_adamw_step",
-           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_enable"]
+           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_enable", "vk_concap_batch"]
 
 
 def check(rc):

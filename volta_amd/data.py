@@ -50,3 +50,49 @@ def model_args(b):
     """Positional arguments in the order of the reference driver's call (train_concap.py:286-289)."""
     return (b["input_ids"], b["image_feat"], b["image_loc"], b["segment_ids"], b["input_mask"], b["image_mask"], b["lm_label_ids"],
             b["image_label"], b["image_cls"], None, None, None, None, None, b["is_match"])
+
+
+class ConceptCapBatchProducer:
+    """Device-side counterpart of the reference's BertPreprocessBatch + ConceptCapLoaderTrain batch assembly
+    (volta/datasets/concept_cap_dataset.py:229-286, 403-668): raw per-pair records already on the GPU -> the tensors of
+    `model_args`.  `captions`: list of token-id lists (no [CLS] / [SEP]); records: `feat [B, R, F]`, `cls [B, R, C]`, `boxes [B, R, 4]`
+    (pixels), `num_boxes [B]`, `img_wh [B, 2]`, `cap_index [B]`.  One call = three HIP launches (csrc/concap.hip)."""
+
+    def __init__(self, captions, seq_len, region_len, vocab_size, add_global_imgfeat="first", objective=1, cls_id=101, sep_id=102, mask_id=103,
+                 device="cuda"):
+        from . import _lib as L
+        self.L = L
+        self.T, self.R, self.V = int(seq_len), int(region_len), int(vocab_size)
+        self.add_global = {None: 0, "first": 1, "last": 2}[add_global_imgfeat]
+        self.objective, self.ids = int(objective), (int(cls_id), int(sep_id), int(mask_id))
+        ld = max(1, max(len(c) for c in captions))
+        tok = torch.zeros(len(captions), ld, dtype=torch.int32)
+        for i, c in enumerate(captions):
+            tok[i, :len(c)] = torch.tensor(c, dtype=torch.int32)
+        self.cap_tokens = tok.to(device)
+        self.cap_len = torch.tensor([len(c) for c in captions], dtype=torch.int32, device=device)
+        self.device = device
+
+    def __call__(self, feat, cls, boxes, num_boxes, img_wh, cap_index, seed):
+        L, C = self.L, __import__("ctypes")
+        B, R, F = feat.shape
+        assert R == self.R and boxes.shape == (B, R, 4) and cls.shape[:2] == (B, R)
+        Cn = cls.shape[2]
+        Rv = R + (1 if self.add_global else 0)
+        dev = feat.device
+        i64 = dict(dtype=torch.int64, device=dev)
+        out = dict(input_ids=torch.empty(B, self.T, **i64), input_mask=torch.empty(B, self.T, **i64), segment_ids=torch.empty(B, self.T, **i64),
+                   lm_label_ids=torch.empty(B, self.T, **i64), is_match=torch.empty(B, **i64), image_feat=torch.empty(B, Rv, F, device=dev),
+                   image_loc=torch.empty(B, Rv, 5, device=dev), image_cls=torch.empty(B, R, Cn, device=dev), image_label=torch.empty(B, R, **i64),
+                   image_mask=torch.empty(B, Rv, **i64))
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).contiguous()
+        i32 = lambda t: t.to(device=dev, dtype=torch.int32).contiguous()
+        keep = [f32(feat), f32(cls), f32(boxes), i32(num_boxes), f32(img_wh), i32(cap_index)]
+        a = L.ConcapArgs(L.ptr(self.cap_tokens), L.ptr(self.cap_len), L.ptr(keep[5]), L.ptr(keep[0]), L.ptr(keep[1]), L.ptr(keep[2]), L.ptr(keep[3]),
+                         L.ptr(keep[4]), *[L.ptr(out[k]) for k in ("input_ids", "input_mask", "segment_ids", "lm_label_ids", "is_match", "image_feat",
+                                                                    "image_loc", "image_cls", "image_label", "image_mask")],
+                         C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), B, self.T, R, F, Cn, self.cap_tokens.shape[0], self.cap_tokens.shape[1], self.V,
+                         self.ids[0], self.ids[1], self.ids[2], self.add_global, self.objective)
+        L.check(L.lib.vk_concap_batch(C.byref(a), L.stream_ptr()))
+        out["_keep"] = keep          # inputs stay alive until the stream has consumed them
+        return out
