@@ -217,7 +217,7 @@ static int launch_cfg(int epi, const KGroup& g, int total, hipStream_t s) {
     return check_launch("vk_gemm_grouped");
 }
 
-static int g_tile_override = 0;       // tuning hook: 0 = heuristic, 128 / 256 / 257 = force 128x128 / 256x256 8-phase / legacy 256x256
+static int g_tile_override = 0;       // tuning hook: 0 = heuristic, 128 / 256 / 258 / 259 force a geometry (see vk_gemm_grouped)
 static int g_stagger = 1;
 static int g_min_tiles256_tn = 50;   // TN (weight gradients, side stream): fewer, longer workgroups leave more CUs to the critical path (19.71 -> 19.54 ms)
 static int g_min_tiles256 = 160;   // fewest 256 x 256 tiles for which that geometry is chosen (256 CUs)
@@ -253,8 +253,6 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
         if ((epilogue == VK_EPI_MULR || epilogue == VK_EPI_ADDR) && !q.R) return set_error("vk_gemm_grouped: R missing");
         if (epilogue == VK_EPI_GELU && !q.C2) return set_error("vk_gemm_grouped: C2 missing");
     }
-    // Tile choice: 256 x 256 whenever that still yields >= 160 workgroups (256 CUs), else 128 x 128.
-    // Tuning hook values: 128, 256, 257 (= the legacy 16-wave 256 x 256 kernel, kept for A/B runs).
     static const bool env_once = [] {       // tuning overrides from the environment (tools only; unset in production)
         if (const char* e = getenv("VK_GEMM_MIN_TILES256")) g_min_tiles256 = atoi(e);
         if (const char* e = getenv("VK_GEMM_MIN_TILES256_TN")) g_min_tiles256_tn = atoi(e);
@@ -263,7 +261,7 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
     }();
     (void)env_once;
     // Geometry (tuning hook values in brackets): 128 x 128 [128], 256 x 256 K-split [258], 256 x 192 K-split [259],
-    // 256 x 256 4-phase [256], legacy 16-wave 256 x 256 [257].  The heuristic takes 256-row tiles whenever they still
+    // 256 x 256 4-phase [256].  The heuristic takes 256-row tiles whenever they still
     // yield >= g_min_tiles256 workgroups, and of the two widths the one with less work on the busiest CU:
     // rounds(tiles / 256 CUs) x tile width.  N = 768 -> 4 column tiles of 192 instead of 3 of 256 (228 instead of
     // 171 workgroups for the ViLBERT row counts: one round of smaller tiles), N = 2304 -> 12 instead of 9.
@@ -283,6 +281,7 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
             if (ea >= 0x7FFFFFF0ull || eb >= 0x7FFFFFF0ull) { edge = 128; break; }     // the LDS-DMA kernels address operands below 2 GiB
         }
     }
+    if (edge != 256 && edge != 258 && edge != 259) edge = 128;
     const int bm = edge == 128 ? 128 : 256, bn = edge == 259 ? 192 : bm;
     KGroup g;
     g.nprob = nprob;
@@ -302,11 +301,7 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
     if (total == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     if (edge == 256 || edge == 258 || edge == 259) return launch_gemm256(layout, epilogue, g, total, s, edge == 258 ? 4 : edge == 259 ? 3 : 0);
-    if (edge == 257) {
-        if (layout == VK_NT) return launch_cfg<false, false, 4, 4, false>(epilogue, g, total, s);
-        if (layout == VK_NN) return launch_cfg<false, true, 4, 4, false>(epilogue, g, total, s);
-        if (layout == VK_TN) return launch_cfg<true, true, 4, 4, false>(epilogue, g, total, s);
-    } else {
+    {
         const bool reg = g_regstage_override >= 0 ? g_regstage_override != 0 : layout != VK_NT;
         if (layout == VK_NT) return reg ? launch_cfg<false, false, 2, 2, true>(epilogue, g, total, s) : launch_cfg<false, false, 2, 2, false>(epilogue, g, total, s);
         if (layout == VK_NN) return reg ? launch_cfg<false, true, 2, 2, true>(epilogue, g, total, s) : launch_cfg<false, true, 2, 2, false>(epilogue, g, total, s);
