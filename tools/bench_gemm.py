@@ -57,11 +57,12 @@ def sweep():
 
 
 def ablate():
-    """Ablation of the 256 x 256 kernel's main loop: what does a K-tile cost without its DMA / MFMA / LDS reads?"""
+    """Ablation of the 4-phase 256 x 256 kernel's main loop (tile 256, the only one that carries the switches): what does a K-tile cost
+    without its DMA / MFMA / LDS reads?"""
     import ctypes
     L.lib.vk_gemm_set_tile.argtypes = [ctypes.c_int]
     L.lib.vk_gemm_set_debug.argtypes = [ctypes.c_int]
-    L.lib.vk_gemm_set_tile(int(sys.argv[2]) if len(sys.argv) > 2 else 256)
+    L.lib.vk_gemm_set_tile(256)
     for dbg, tag in ((0, "full"), (1, "no DMA in loop"), (2, "no MFMA"), (4, "no LDS reads"), (3, "no DMA, no MFMA"), (5, "no DMA, no LDS reads"), (6, "no MFMA, no LDS reads"), (7, "barriers only"), (16, "exit at once"), (7 + 32, "no K loop"), (7 + 32 + 8, "no K loop, no epilogue"), (7 + 8, "barriers only, no epilogue"), (8, "no epilogue"), (0, "full")):
         L.lib.vk_gemm_set_debug(dbg)
         print("=== ablation:", tag, flush=True)

@@ -300,11 +300,7 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
     strip_offsets<BT>(offB, P.ldb, n0, BN, tid);
     const uint32_t kA = AT ? 64u * (uint32_t)P.lda : 64u, kB = BT ? 64u * (uint32_t)P.ldb : 64u;     // bytes per 32-deep K-step
     const int np = (K + 31) / 32;
-    const int dbg = g.stagger >> 8;
-    bool in_loop = false;
-
     auto stage = [&](int p, int slot) {
-        if ((dbg & 1) && in_loop) return;
         const bool live = p < np;
         const uint32_t sa = lds0 + (uint32_t)slot * 2u * HT;
         stage_half(rsA, sa, offA, live ? (uint32_t)p * kA : OOB, wave);
@@ -328,36 +324,30 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
     VK_WAIT_DMA();
     VK_SYNC();
     if (wr == 1) VK_SYNC();        // the upper half of the workgroup runs half a phase behind
-    in_loop = true;
-
     int rd = 0, wrs = 3;           // ring slots of the K-step read / staged in this phase
     for (int p = 0; p < np; ++p) {
         const uint32_t sa = lds0 + (uint32_t)rd * 2u * HT, sb = sa + HT;
         bf16x8 a[8], b[TJ];
-        if (!(dbg & 4)) {
 #pragma unroll
-            for (int j = 0; j < TJ; ++j) b[j] = BT ? frag_cols<512>(sb, wc * WN + j * 16, 0, lane) : frag_strip(sb, wc * WN + j * 16, lane);
-            __builtin_amdgcn_sched_barrier(0);
+        for (int j = 0; j < TJ; ++j) b[j] = BT ? frag_cols<512>(sb, wc * WN + j * 16, 0, lane) : frag_strip(sb, wc * WN + j * 16, lane);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < 8; ++i) a[i] = AT ? frag_cols<512>(sa, wr * 128 + i * 16, 0, lane) : frag_strip(sa, wr * 128 + i * 16, lane);
-        }
+        for (int i = 0; i < 8; ++i) a[i] = AT ? frag_cols<512>(sa, wr * 128 + i * 16, 0, lane) : frag_strip(sa, wr * 128 + i * 16, lane);
         stage(p + 3, wrs);
         VK_WAIT_DMA();
         VK_SYNC();
         VK_WAIT_LDS();
-        if (!(dbg & 2)) {
-            __builtin_amdgcn_s_setprio(1);
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-            for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < 8; ++i)
 #pragma unroll
-                for (int j = 0; j < TJ; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
-            if (BG && do_bias_grad) {
+            for (int j = 0; j < TJ; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+        if (BG && do_bias_grad) {
 #pragma unroll
-                for (int i = 0; i < 8; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i], accb[i], 0, 0, 0);
-            }
-            __builtin_amdgcn_s_setprio(0);
+            for (int i = 0; i < 8; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i], accb[i], 0, 0, 0);
         }
+        __builtin_amdgcn_s_setprio(0);
         VK_SYNC();
         rd = rd == RING - 1 ? 0 : rd + 1;
         wrs = wrs == RING - 1 ? 0 : wrs + 1;
