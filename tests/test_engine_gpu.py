@@ -52,10 +52,20 @@ def rel_err(a, b):
 @pytest.mark.parametrize("name", list(CONFIGS))
 @pytest.mark.parametrize("train", [False, True])
 def test_forward_backward_parity(name, train):
+    _parity(name, train, 4, 20, 36)
+
+
+@pytest.mark.parametrize("T,Rn", [(38, 36), (20, 100), (64, 127)])
+def test_forward_backward_parity_other_lengths(T, Rn):
+    """The reference's own caption length (38, examples/ctrl_vilbert/concap/train.sh:16), VL-BERT's 100 regions and the largest shapes
+    the attention tiles hold (64 text tokens, 128 region rows): the 64-row text / 128-row vision attention tile variants end to end."""
+    _parity("vilbert", True, 4, T, Rn, batch_seed=9)      # (seed 7 leaves the (64, 127) batch without a single labelled row)
+
+
+def _parity(name, train, B, T, Rn, batch_seed=7):
     from oracle import volta_ref as R
     model, rcfg, sd = build(name)
-    B, T, Rn = 4, 20, 36
-    batch = R.synthetic_batch(rcfg, B, T, Rn, seed=7, pad=True)
+    batch = R.synthetic_batch(rcfg, B, T, Rn, seed=batch_seed, pad=True)
     seed = 0xABCDEF12345
     model.train(train)
     model.set_dropout_seed(seed)
