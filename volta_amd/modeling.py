@@ -9,6 +9,7 @@ Differences a caller can observe, all deliberate:
   * activations are bf16 with fp32 accumulation / statistics (north_star), parameters stay fp32;
   * dropout uses a counter-based Philox stream seeded from `torch.initial_seed()` (or `set_dropout_seed`).
 """
+import logging
 import os
 
 import torch
@@ -16,6 +17,8 @@ from torch import nn
 
 from . import modules as M
 from .config import BertConfig
+
+logger = logging.getLogger(__name__)
 
 
 class PreTrainedModel(nn.Module):
@@ -239,7 +242,7 @@ class BertForVLPreTraining(PreTrainedModel):
         self.bert = BertModel(config)
         self.cls = BertPreTrainingHeads(config, self.bert.embeddings.word_embeddings.weight)
         self.visual_target_weights = config.visual_target_weights
-        print("model's visual targets are ", [ix for ix, w in config.visual_target_weights.items() if w > 0])
+        logger.info("model's visual targets are %s", [ix for ix, w in config.visual_target_weights.items() if w > 0])
         self.add_global_imgfeat = int(config.add_global_imgfeat is not None)
         self.tie_weights()
         self.__dict__["_arena"] = None
