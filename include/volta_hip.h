@@ -23,7 +23,7 @@ const char* vk_last_error(void);           /* thread-local message of the last f
 
 /* ------------------------------------------------------------------------------------------------
  * Dropout stream.  Replaces torch.nn.Dropout's global generator (volta/encoders.py:207,218,377,391,
- * 519,534; volta/embeddings.py:53,137,...) with a counter-based Philox-4x32-10 stream: element
+ * 519,534; volta/embeddings.py:53,137,...) with a counter-based Philox-4x32-7 stream: element
  * (row, c) of dropout site `site` takes word c&3 of philox(counter=(c>>2,row,site,0), key=*seed).
  * `seed` lives in device memory so that a captured hipGraph replays with fresh randomness. */
 typedef struct vk_dropout {

@@ -117,20 +117,22 @@ class Dropper:
         return x * keep.to(x.dtype) * (1.0 / (1.0 - p))
 
 
-# Philox-4x32-10 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3").  Engine contract
+# Philox-4x32 (Salmon et al., "Parallel random numbers: as easy as 1, 2, 3").  Engine contract
 # (volta_amd/csrc/common.h): a dropout site views its tensor as [rows, C] (C = last dim); element
-# (row, c) takes word c&3 of philox(counter=(c>>2, row, site, 0), key=(seed_lo, seed_hi)) and is
-# kept iff word >= floor(p*2^32).
+# (row, c) takes word c&3 of Philox-4x32-7(counter=(c>>2, row, site, 0), key=(seed_lo, seed_hi)) and is
+# kept iff word >= floor(p*2^32).  7 rounds (the smallest Crush-resistant variant) for the dropout streams,
+# the default 10 for the batch producer's sampling policy and the known-answer vectors.
+DROPOUT_PHILOX_ROUNDS = 7
 _PH_M0, _PH_M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
 _PH_W0, _PH_W1 = np.uint32(0x9E3779B9), np.uint32(0xBB67AE85)
 
 
-def philox_raw(c0, c1, c2, c3, k0, k1):
-    """Vectorised Philox4x32-10: uint32 arrays (same shape) -> uint32[..., 4]."""
+def philox_raw(c0, c1, c2, c3, k0, k1, rounds=10):
+    """Vectorised Philox4x32-<rounds>: uint32 arrays (same shape) -> uint32[..., 4]."""
     c0, c1, c2, c3 = (np.asarray(c, np.uint32) for c in (c0, c1, c2, c3))
     k0, k1 = np.uint32(k0), np.uint32(k1)
     with np.errstate(over="ignore"):
-        for _ in range(10):
+        for _ in range(rounds):
             p0 = _PH_M0 * c0.astype(np.uint64)
             p1 = _PH_M1 * c2.astype(np.uint64)
             hi0, lo0 = (p0 >> np.uint64(32)).astype(np.uint32), p0.astype(np.uint32)
@@ -147,7 +149,7 @@ def philox_u32(seed, site, rows, C):
     c0 = np.broadcast_to(np.arange(nb, dtype=np.uint32)[None, :], (rows, nb))
     c1 = np.broadcast_to(np.arange(rows, dtype=np.uint32)[:, None], (rows, nb))
     w = philox_raw(c0, c1, np.full((rows, nb), site, np.uint32), np.zeros((rows, nb), np.uint32),
-                   seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)
+                   seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, rounds=DROPOUT_PHILOX_ROUNDS)
     return w.reshape(rows, nb * 4)[:, :C]
 
 

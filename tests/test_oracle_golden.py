@@ -158,14 +158,20 @@ def test_warmup_linear_schedule():
 
 
 def test_philox_known_answer():
-    """Philox4x32-10 known-answer vectors (Random123 kat_vectors): counter 0/key 0 and all-ones."""
+    """Philox4x32 known-answer vectors (Random123 kat_vectors): counter 0/key 0, all-ones and the pi digits."""
     z = np.zeros(1, np.uint32)
     assert [hex(int(x)) for x in R.philox_raw(z, z, z, z, 0, 0)[0]] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
     f = np.full(1, 0xFFFFFFFF, np.uint32)
     assert [hex(int(x)) for x in R.philox_raw(f, f, f, f, 0xFFFFFFFF, 0xFFFFFFFF)[0]] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
-    # engine contract: element (row, c) of a [rows, C] site = word c&3 of counter (c>>2, row, site, 0)
+    # the 7-round variant of the dropout streams (same kat_vectors file, "philox4x32 7" lines)
+    assert [hex(int(x)) for x in R.philox_raw(z, z, z, z, 0, 0, rounds=7)[0]] == ["0x5f6fb709", "0xd893f64", "0x4f121f81", "0x4f730a48"]
+    assert [hex(int(x)) for x in R.philox_raw(f, f, f, f, 0xFFFFFFFF, 0xFFFFFFFF, rounds=7)[0]] == ["0x5207ddc2", "0x45165e59", "0x4d8ee751", "0x8c52f662"]
+    a = lambda v: np.array([v], np.uint32)
+    assert [hex(int(x)) for x in R.philox_raw(a(0x243f6a88), a(0x85a308d3), a(0x13198a2e), a(0x03707344), 0xa4093822, 0x299f31d0, rounds=7)[0]] == \
+        ["0x4dfccaba", "0x190a87f0", "0xc47362ba", "0xb6b5242a"]
+    # engine contract: element (row, c) of a [rows, C] site = word c&3 of Philox-4x32-7(counter (c>>2, row, site, 0))
     u = R.philox_u32(0x1234567800000042, 5, 3, 10)
-    w = R.philox_raw(np.array([2], np.uint32), np.array([1], np.uint32), np.array([5], np.uint32), z, 0x42, 0x12345678)[0]
+    w = R.philox_raw(np.array([2], np.uint32), np.array([1], np.uint32), np.array([5], np.uint32), z, 0x42, 0x12345678, rounds=R.DROPOUT_PHILOX_ROUNDS)[0]
     assert int(u[1, 9]) == int(w[1])
     keep = R.philox_keep_mask(1234, 3, (1000, 100), 0.1)
     assert abs(float(keep.float().mean()) - 0.9) < 5e-3

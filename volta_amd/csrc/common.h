@@ -35,21 +35,33 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// ---- Philox-4x32-10: the engine's dropout stream ----------------------------------------------
-// Contract (mirrored by oracle/volta_ref.py:philox_u32): a dropout site sees its tensor as
-// [rows, C]; element (row, c) takes word (c & 3) of philox(counter = (c >> 2, row, site, 0),
+// ---- Philox-4x32: the engine's counter-based random streams ------------------------------------
+// Dropout contract (mirrored by oracle/volta_ref.py:philox_u32): a dropout site sees its tensor as
+// [rows, C]; element (row, c) takes word (c & 3) of Philox-4x32-7(counter = (c >> 2, row, site, 0),
 // key = (seed_lo, seed_hi)); it is KEPT iff word >= floor(p * 2^32) and scaled by 1/(1-p).
-__device__ __forceinline__ u32x4 philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+// 7 rounds is the smallest Crush-resistant Philox-4x32 (Salmon et al., SC'11, table 2); the dropout kernels
+// (LayerNorm, attention) are VALU-bound on this generator, and the 10-round form cost them 40-75 % of their
+// instructions.  The sampling policy of the batch producer (concap.hip) keeps the 10-round default form.
+// The products are written as v_mul_hi_u32 + v_mul_lo_u32 pairs on purpose: the 64-bit form (v_mad_u64_u32) needs
+// aligned register pairs, which pushed the attention forward kernel from 121 to 134 VGPRs (3 instead of 4 waves
+// per SIMD) and made it 25 % slower.
+template <int ROUNDS>
+__device__ __forceinline__ u32x4 philox4_rounds(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
 #pragma unroll
-    for (int i = 0; i < 10; ++i) {
-        uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+    for (int i = 0; i < ROUNDS; ++i) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
         k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
     }
     u32x4 r = {c0, c1, c2, c3};
     return r;
+}
+constexpr int DROPOUT_PHILOX_ROUNDS = 7;
+// the dropout stream
+__device__ __forceinline__ u32x4 philox4(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1) {
+    return philox4_rounds<DROPOUT_PHILOX_ROUNDS>(c0, c1, c2, c3, k0, k1);
 }
 
 struct DropCfg {              // by-value kernel argument

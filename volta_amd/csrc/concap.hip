@@ -15,7 +15,7 @@ namespace vk {
 
 constexpr uint32_t CC_T15 = 644245094u;      // floor(0.15 * 2^32): "prob < 0.15"
 __device__ __forceinline__ uint32_t cc_word(uint64_t seed, uint32_t stream, uint32_t pair, uint32_t slot) {
-    return philox4(slot, pair, stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32))[0];
+    return philox4_rounds<10>(slot, pair, stream, 0u, (uint32_t)seed, (uint32_t)(seed >> 32))[0];
 }
 // the reference compares prob / 0.15 with 0.8 / 0.9 in double precision on prob = word / 2^32
 __device__ __forceinline__ double cc_sub(uint32_t w) { return ((double)w / 4294967296.0) / 0.15; }

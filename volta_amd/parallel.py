@@ -48,14 +48,20 @@ class BucketReducer:
         self.stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
         self.use_avg = self.cuda and dist.get_backend(process_group) == "nccl"
 
-    def reduce(self, ranges):
+    def reduce(self, ranges, join=None):
+        """`join`: called with the communication stream current, to make IT (not the compute stream) wait for other
+        producers of the bucket (the executor's weight-gradient side stream)."""
         if self.cuda:
             ev = torch.cuda.Event()
             ev.record()
             with torch.cuda.stream(self.stream):
                 self.stream.wait_event(ev)
+                if join is not None:
+                    join()
                 self._reduce(ranges)
         else:
+            if join is not None:
+                join()
             self._reduce(ranges)
 
     def _reduce(self, ranges):
@@ -107,8 +113,9 @@ class DistributedDataParallel(nn.Module):
         start = 0
         for end, ranges in self._plan(eng):
             eng.bwd.run(start, end)
-            eng.bwd.join_side()          # the bucket's weight gradients were computed on the executor's side stream
-            self.reducer.reduce(ranges)
+            # the bucket's weight gradients were computed on the executor's side stream: the communication stream waits
+            # for them, the compute stream carries on with the backward
+            self.reducer.reduce(ranges, join=eng.bwd.join_side)
             start = end
         eng.bwd.run(start, len(eng.bwd.ops))
         self.reducer.finish()
