@@ -75,7 +75,7 @@ void gemm_kernel(const KGroup g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
 
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = (g.stagger & GROUP_PLAIN_ORDER) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < VK_GEMM_MAX_GROUP; ++i)
@@ -183,7 +183,7 @@ void gemm_kernel(const KGroup g) {
         // Waves 4..7 and 12..15 of a 16-wave workgroup share their SIMDs with waves 0..3 / 8..11: they issue the DMA of
         // the next tile after their first 16 MFMAs instead of before them, so that on every SIMD two waves feed the
         // matrix pipe while the other two pay the LDS-DMA issue cost (60-185 cycles per piece).
-        const bool late = g.stagger && (WM * WN > 4) && ((__builtin_amdgcn_readfirstlane(wave) >> 2) & 1);   // SIMD partners: w, w+4, ...
+        const bool late = (g.stagger & 0xFF) && (WM * WN > 4) && ((__builtin_amdgcn_readfirstlane(wave) >> 2) & 1);   // SIMD partners: w, w+4, ...
         for (int kt = 0; kt < nk; ++kt) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();          // tile kt landed for every wave; everyone is done reading tile kt-1
@@ -285,7 +285,11 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
     const int bm = edge == 128 ? 128 : 256, bn = edge == 259 ? 192 : bm;
     KGroup g;
     g.nprob = nprob;
-    g.stagger = g_stagger | (g_debug << 8);
+    g.stagger = (g_stagger & 0xFF) | ((g_debug & 0xFF) << 8);
+    // Problems with a device-side row count (heads on labelled rows) keep only their first few row tiles alive; the
+    // XCD-chunked order would hand all of them to XCD 0 (LM decoder: 240 live tiles on 32 CUs, 188 us instead of ~40).
+    for (int i = 0; i < nprob; ++i)
+        if (probs[i].dyn) g.stagger |= GROUP_PLAIN_ORDER;
     int total = 0;
     for (int i = 0; i < nprob; ++i) {
         const vk_gemm_problem& q = probs[i];

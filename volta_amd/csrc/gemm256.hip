@@ -78,7 +78,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const KGroup g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = (g.stagger & GROUP_PLAIN_ORDER) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < VK_GEMM_MAX_GROUP; ++i)
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const KGroup g) {
     const uint32_t sA = AT ? 128u : 128u * (uint32_t)P.lda, kA = AT ? 128u * (uint32_t)P.lda : 128u;   // bytes per sub-tile / K-tile
     const uint32_t sB = BT ? 64u : 64u * (uint32_t)P.ldb, kB = BT ? 128u * (uint32_t)P.ldb : 128u;
     const int nk = (K + BK - 1) / BK;
-    const int dbg = g.stagger >> 8;               // ablation switches (tools/bench_gemm.py): 1 no DMA, 2 no MFMA, 4 no LDS reads, 8 no epilogue, 16 exit at once, 32 no K loop
+    const int dbg = (g.stagger >> 8) & 0xFF;               // ablation switches (tools/bench_gemm.py): 1 no DMA, 2 no MFMA, 4 no LDS reads, 8 no epilogue, 16 exit at once, 32 no K loop
     bool in_loop = false;
     if (dbg & 16) return;
 
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
 
-    const int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int bid = (g.stagger & GROUP_PLAIN_ORDER) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < VK_GEMM_MAX_GROUP; ++i)

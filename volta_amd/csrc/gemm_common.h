@@ -15,9 +15,10 @@ struct KProb {
     int32_t M, N, K, lda, ldb, ldc, ldr, n_store;
     int32_t tiles_n, tile_start;
 };
+constexpr int GROUP_PLAIN_ORDER = 1 << 16;    // KGroup::stagger flag: workgroup i takes tile i (no XCD chunking)
 struct KGroup {
     int32_t nprob;
-    int32_t stagger;   // 128^2 / legacy geometries: half of the waves of each SIMD issue their LDS-DMA late
+    int32_t stagger;   // bits 0-7: DMA stagger of the legacy geometries, 8-15: ablation switches (study kernel), 16: GROUP_PLAIN_ORDER
     KProb p[VK_GEMM_MAX_GROUP];
 };
 
