@@ -1,6 +1,8 @@
+# Step time of every BASELINE configuration on one GPU (writes gpurun_out/cfg_*.json, prints a summary line each).
 set -e
+mkdir -p gpurun_out
 run() { tag=$1; shift; timeout -k 10 250 python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-timing "$@" > gpurun_out/cfg_$tag.json 2> gpurun_out/cfg_$tag.err; python3 -c "
-import json,sys; d=json.loads(open('gpurun_out/cfg_$tag.json').read().strip().splitlines()[-1]); print('$tag', round(d['ms_per_step'],2), 'ms', round(d['value']), 'pairs/s', 'frac', round(d['roofline']['frac'],4))"; }
+import json,sys; d=json.loads(open('gpurun_out/cfg_$tag.json').read().strip().splitlines()[-1]); print('$tag', round(d['ms_per_step'],2), 'ms', round(d['value']), 'pairs/s', 'frac', round(d.get('roofline',{}).get('frac',0),4))"; }
 run vilbert_b256
 run vilbert_b512 --batch 512
 run vilbert_t38 --seq-len 38

@@ -73,15 +73,29 @@ def concap(B=256, T=20, Rl=36, F=2048, Cn=1601):
 
 
 if __name__ == "__main__":
-    concap()
     import ctypes
-    ln(5120)
-    ln(9472)
+    if not (len(sys.argv) > 1 and sys.argv[1] == "fwd"):
+        concap()
+        ln(5120)
+        ln(9472)
     L.lib.vk_attn_set_bwd_occupancy.argtypes = [ctypes.c_int]
     L.lib.vk_attn_set_bwd_waves.argtypes = [ctypes.c_int]
-    for wv in (4, 8, 5):
+    L.lib.vk_attn_set_fwd_occupancy.argtypes = [ctypes.c_int]
+    L.lib.vk_attn_set_fwd_waves.argtypes = [ctypes.c_int]
+    if len(sys.argv) > 1 and sys.argv[1] == "fwd":          # forward occupancy study
+        for occ, wv in ((4, 0), (4, 4), (5, 0), (5, 4), (4, 0)):
+            L.lib.vk_attn_set_fwd_occupancy(occ)
+            L.lib.vk_attn_set_fwd_waves(wv)
+            print("--- attn fwd: waves per SIMD targeted", occ, " waves per workgroup", wv or "one per query tile")
+            attn([[1, 0], [0, 0]])
+            attn([[1, 0], [0, 1]])
+            attn([[0, 1], [1, 0]])
+            attn([[1, 1], [1, 1]], T=20, R=37)
+        sys.exit(0)
+    for occ, wv in ((2, 4), (3, 4), (2, 8), (2, 4)):
+        L.lib.vk_attn_set_bwd_occupancy(occ)
         L.lib.vk_attn_set_bwd_waves(wv)
-        print("--- attn bwd waves per workgroup", wv)
+        print("--- attn bwd: waves per SIMD targeted", occ, " waves per workgroup", wv)
         attn([[1, 0], [0, 0]])
         attn([[1, 0], [0, 1]])
         attn([[0, 1], [1, 0]])

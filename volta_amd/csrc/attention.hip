@@ -126,8 +126,8 @@ struct AttnK {                       // kernel-side copy of vk_attn_args (+ back
 template <int P0, int P1> struct Pads { static constexpr int P[2] = {P0, P1}; };
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int TP, int RP>
-__global__ __launch_bounds__(512) void attn_fwd_kernel(const AttnK a) {
+template <int TP, int RP, int OCC>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void attn_fwd_kernel(const AttnK a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(VK_LDS char*)smem;
     constexpr int NKT[2] = {TP / 16, RP / 16};
@@ -468,24 +468,28 @@ static int fill(AttnK& k, const vk_attn_args* a, const vk_attn_bwd_args* bw) {
     return 0;
 }
 
+static int g_attn_fwd_waves = 4;    // waves per workgroup (query tiles are looped): 4 workgroups of 4 waves fill the CU's 16 wave slots, one wave per tile (5) leaves it at 3 workgroups (measured -18 %)
+static int g_attn_fwd_occ = 4;      // tuning hook: waves per SIMD the register allocation targets (5 spills 16-74 dwords: slower)
 template <int TP, int RP>
 static int launch_fwd(const AttnK& k, int nq_tiles, hipStream_t s) {
     const int lds = 2 * (TP + RP) * 128;
     int waves = nq_tiles < 4 ? 4 : (nq_tiles > 8 ? 8 : nq_tiles);      // staging is sized for >= 256 threads
-    hipLaunchKernelGGL((attn_fwd_kernel<TP, RP>), dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
+    if (g_attn_fwd_waves >= 4 && g_attn_fwd_waves < waves && 4 * lds <= 160 * 1024) waves = g_attn_fwd_waves;     // only where four workgroups fit the CU's LDS
+    if (g_attn_fwd_occ == 5) hipLaunchKernelGGL((attn_fwd_kernel<TP, RP, 5>), dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
+    else hipLaunchKernelGGL((attn_fwd_kernel<TP, RP, 4>), dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
     return check_launch("vk_gated_attn_fwd");
 }
 static int g_attn_bwd_waves = 4;    // waves per workgroup (tasks are looped): 4 lets two workgroups share a CU (measured -15 %)
-static int g_attn_bwd_occ = 2;      // tuning hook (tools/bench_small.py); 3 measured slower (spills), kept for reference
+static int g_attn_bwd_occ = 3;      // waves per SIMD the register allocation targets: 3 (<= 168 VGPRs, a few spilled dwords) lets three 4-wave workgroups share a CU (-3..-9 % against 2)
 
 template <int TP, int RP>
 static int launch_bwd(const AttnK& k, int ntasks, hipStream_t s) {
     const int lds = 4 * (TP + RP) * 128 + 2 * (TP + RP) * 4;
-    if (g_attn_bwd_occ == 3) {
+    if (g_attn_bwd_occ == 3 && 3 * lds <= 160 * 1024) {       // three workgroups only fit with the small images
         auto kern = attn_bwd_kernel<TP, RP, 3>;
         static bool once = false;
         if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
-        int waves = ntasks < 4 ? 4 : (ntasks > 5 ? 5 : ntasks);
+        int waves = g_attn_bwd_waves < 4 ? 4 : (ntasks > g_attn_bwd_waves ? g_attn_bwd_waves : (ntasks < 4 ? 4 : ntasks));
         hipLaunchKernelGGL(kern, dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
     } else {
         auto kern = attn_bwd_kernel<TP, RP, 2>;
@@ -533,3 +537,5 @@ extern "C" int vk_gated_attn_bwd(const vk_attn_args* a, const vk_attn_bwd_args* 
 }
 extern "C" void vk_attn_set_bwd_occupancy(int v) { vk::g_attn_bwd_occ = v; }
 extern "C" void vk_attn_set_bwd_waves(int v) { vk::g_attn_bwd_waves = v; }
+extern "C" void vk_attn_set_fwd_waves(int v) { vk::g_attn_fwd_waves = v; }
+extern "C" void vk_attn_set_fwd_occupancy(int v) { vk::g_attn_fwd_occ = v; }
