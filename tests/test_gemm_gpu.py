@@ -10,7 +10,7 @@ def _mods():
     return L, ops
 
 
-@pytest.fixture(params=[0, 128, 256, 258, 259], ids=["auto", "tile128x128", "tile256x256", "tile256x256k32", "tile256x192k32"], autouse=True)
+@pytest.fixture(params=[0, 128, 256, 258, 259, 260], ids=["auto", "tile128x128", "tile256x256", "tile256x256k32", "tile256x192k32", "tile256x128k32"], autouse=True)
 def tile_edge(request):
     """Every GEMM test runs under the tile heuristic and with each tile geometry forced."""
     import ctypes

@@ -38,7 +38,7 @@ def sweep():
     """A/B of the tile geometries in one process: 128 x 128, 256 x 256 8-phase, legacy 16-wave 256 x 256."""
     import ctypes
     L.lib.vk_gemm_set_tile.argtypes = [ctypes.c_int]
-    for edge in (258, 259, 256, 128, 258):
+    for edge in ([int(x) for x in sys.argv[2:]] or (258, 259, 256, 128, 258)):
         L.lib.vk_gemm_set_tile(edge)
         print("=== tile", edge, flush=True)
         for Mrows, tag in ((5120, "text"), (9472, "vis")):

@@ -260,7 +260,7 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
         return true;
     }();
     (void)env_once;
-    // Geometry (tuning hook values in brackets): 128 x 128 [128], 256 x 256 K-split [258], 256 x 192 K-split [259],
+    // Geometry (tuning hook values in brackets): 128 x 128 [128], 256 x 256 K-split [258], 256 x 192 K-split [259], 256 x 128 K-split [260, study only: never faster than 128 x 128 on the model shapes],
     // 256 x 256 4-phase [256].  The heuristic takes 256-row tiles whenever they still
     // yield >= g_min_tiles256 workgroups, and of the two widths the one with less work on the busiest CU:
     // rounds(tiles / 256 CUs) x tile width.  N = 768 -> 4 column tiles of 192 instead of 3 of 256 (228 instead of
@@ -274,15 +274,15 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
             edge = c192 < 0.97 * c256 ? 259 : 258;
         }
     }
-    if (edge == 256 || edge == 258 || edge == 259) {
+    if (edge == 256 || edge == 258 || edge == 259 || edge == 260) {
         for (int i = 0; i < nprob; ++i) {
             const vk_gemm_problem& q = probs[i];
             const uint64_t ea = (uint64_t)(layout == VK_TN ? q.K : q.M) * q.lda * 2, eb = (uint64_t)(layout == VK_NT ? q.N : q.K) * q.ldb * 2;
             if (ea >= 0x7FFFFFF0ull || eb >= 0x7FFFFFF0ull) { edge = 128; break; }     // the LDS-DMA kernels address operands below 2 GiB
         }
     }
-    if (edge != 256 && edge != 258 && edge != 259) edge = 128;
-    const int bm = edge == 128 ? 128 : 256, bn = edge == 259 ? 192 : bm;
+    if (edge != 256 && edge != 258 && edge != 259 && edge != 260) edge = 128;
+    const int bm = edge == 128 ? 128 : 256, bn = edge == 259 ? 192 : edge == 260 ? 128 : bm;
     KGroup g;
     g.nprob = nprob;
     g.stagger = (g_stagger & 0xFF) | ((g_debug & 0xFF) << 8);
@@ -304,7 +304,7 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
     }
     if (total == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (edge == 256 || edge == 258 || edge == 259) return launch_gemm256(layout, epilogue, g, total, s, edge == 258 ? 4 : edge == 259 ? 3 : 0);
+    if (edge == 256 || edge == 258 || edge == 259 || edge == 260) return launch_gemm256(layout, epilogue, g, total, s, edge == 258 ? 4 : edge == 259 ? 3 : edge == 260 ? 2 : 0);
     {
         const bool reg = g_regstage_override >= 0 ? g_regstage_override != 0 : layout != VK_NT;
         if (layout == VK_NT) return reg ? launch_cfg<false, false, 2, 2, true>(epilogue, g, total, s) : launch_cfg<false, false, 2, 2, false>(epilogue, g, total, s);

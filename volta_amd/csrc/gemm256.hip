@@ -359,12 +359,12 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
     gemm_epilogue<AT, EPI, 8, TJ>(P, acc, accb, do_bias_grad, m0 + wr * 128, n0 + wc * WN, M, lane, lds0 + (uint32_t)wave * 16384u);
 }
 
-template <bool AT, bool BT, int KSPLIT>      // 0: 4-phase 256 x 256, 4 / 3: K-split kernel with 256 / 192 columns
+template <bool AT, bool BT, int KSPLIT>      // 0: 4-phase 256 x 256, 4 / 3 / 2: K-split kernel with 256 / 192 / 128 columns
 static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s) {
     constexpr int LDS = (KSPLIT ? 10 : 8) * HT;
 #define VK_CASE(E)                                                                                        \
     case E: {                                                                                             \
-        auto k = KSPLIT == 3 ? gemm256k_kernel<AT, BT, E, 3> : KSPLIT == 4 ? gemm256k_kernel<AT, BT, E, 4> : gemm256_kernel<AT, BT, E>; \
+        auto k = KSPLIT == 2 ? gemm256k_kernel<AT, BT, E, 2> : KSPLIT == 3 ? gemm256k_kernel<AT, BT, E, 3> : KSPLIT == 4 ? gemm256k_kernel<AT, BT, E, 4> : gemm256_kernel<AT, BT, E>; \
         static bool once = false;                                                                         \
         if (!once) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; } \
         hipLaunchKernelGGL(k, dim3(total), dim3(512), LDS, s, g);                                         \
@@ -379,6 +379,11 @@ static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s) {
 }
 
 int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant) {
+    if (variant == 2) {
+        if (layout == VK_NT) return launch_layout<false, false, 2>(epilogue, g, total, s);
+        if (layout == VK_NN) return launch_layout<false, true, 2>(epilogue, g, total, s);
+        if (layout == VK_TN) return launch_layout<true, true, 2>(epilogue, g, total, s);
+    }
     if (variant == 3) {
         if (layout == VK_NT) return launch_layout<false, false, 3>(epilogue, g, total, s);
         if (layout == VK_NN) return launch_layout<false, true, 3>(epilogue, g, total, s);

@@ -91,6 +91,7 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
         constexpr int RPH = TIH * 16;
         constexpr int CPR = ROWB / 16;                         // 16-byte chunks per row
         constexpr int RPI = 64 / CPR;                          // rows per store instruction
+        constexpr int SWZ = POW2 ? (CPR < 8 ? CPR - 1 : 7) : 0; // XOR mask of the chunk swizzle (stays inside the row: 4 chunks for 256 x 128 bf16 tiles)
         static_assert(TIH >= 1 && RPH * PITCH * NIMG <= 16384, "epilogue staging does not fit its 16 KiB region");
         const bool via_lds = lds_region != 0 && ((ldc * ES) & 15) == 0 && (((uintptr_t)Cp | (uintptr_t)C2p) & 15) == 0;
         const uint32_t img2 = lds_region + RPH * PITCH;
@@ -134,7 +135,7 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
                 f32x4 v = acc[i][j] + b4[j];
                 if (F32OUT) {
                     if (EPI == VK_EPI_F32_ACC) v += cv[j];
-                    if (via_lds) *(f32x4 VK_LDS*)(uintptr_t)(lds_region + lrow * PITCH + (((j * 4 + gq) ^ (POW2 ? (lrow & 7) : 0)) << 4)) = v;
+                    if (via_lds) *(f32x4 VK_LDS*)(uintptr_t)(lds_region + lrow * PITCH + (((j * 4 + gq) ^ (lrow & SWZ)) << 4)) = v;
                     else *(f32x4*)(Cp + (rowc + j * 16) * 4) = v;
                     continue;
                 }
@@ -151,7 +152,7 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
                 }
                 const u32x2 pk = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
                 if (via_lds) {
-                    const uint32_t a = lrow * PITCH + (((j * 2 + (gq >> 1)) ^ (POW2 ? (lrow & 7) : 0)) << 4) + ((gq & 1) << 3);
+                    const uint32_t a = lrow * PITCH + (((j * 2 + (gq >> 1)) ^ (lrow & SWZ)) << 4) + ((gq & 1) << 3);
                     *(u32x2 VK_LDS*)(uintptr_t)(lds_region + a) = pk;
                     if (EPI == VK_EPI_GELU) *(u32x2 VK_LDS*)(uintptr_t)(img2 + a) = u32x2{pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3])};
                 } else {
@@ -167,7 +168,7 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
                 for (int q = 0; q < (RPH + RPI - 1) / RPI; ++q) {
                     const int row = q * RPI + rr0;
                     if ((RPI * CPR < 64 && rr0 >= RPI) || ((RPH % RPI) && row >= RPH)) continue;
-                    const uint32_t a = row * PITCH + ((ch ^ (POW2 ? (row & 7) : 0)) << 4);
+                    const uint32_t a = row * PITCH + ((ch ^ (row & SWZ)) << 4);
                     const size_t g = ((size_t)(mrow0 + row) * ldc + (size_t)n_base) * ES + (size_t)ch * 16;
                     *(u32x4*)(Cp + g) = *(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a);
                     if (EPI == VK_EPI_GELU) *(u32x4*)(C2p + g) = *(const u32x4 VK_LDS*)(uintptr_t)(img2 + a);
