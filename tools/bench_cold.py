@@ -46,7 +46,8 @@ def main():
     tiny = torch.zeros(64, device="cuda")
     nothing = lambda: None
     for name, layout, Mr, N, K in (("text ffn-down fwd", L.NT, 5120, 768, 3072), ("text out fwd", L.NT, 5120, 768, 768),
-                                   ("text qkv fwd", L.NT, 5120, 2304, 768), ("text+vis-sized qkv", L.NT, 14592, 2304, 768)):
+                                   ("text qkv fwd", L.NT, 5120, 2304, 768), ("text+vis-sized qkv", L.NT, 14592, 2304, 768),
+                                   ("text+vis ffn-down", L.NT, 14592, 768, 3072), ("text+vis ffn-up", L.NT, 14592, 3072, 768)):
         fn, keep = make(layout, L.EPI_BF16, Mr, N, K, 1)
         res = [("itself", timed(fn, fn)), ("nothing (event gap)", timed(fn, nothing)), ("LayerNorm kernel", timed(fn, ln)),
                ("other GEMM template", timed(fn, other)), ("600 MB copy", timed(fn, flush)),
