@@ -86,7 +86,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
 __device__ __forceinline__ void gelu_both(float x, float& y, float& dy) {
     const float ax = fabsf(x);
     const float e = __expf(-0.5f * x * x);
-    const float t = __frcp_rn(1.0f + 0.3275911f * 0.70710678118654752f * ax);
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * 0.70710678118654752f * ax);   // bare v_rcp_f32 (1 ulp): __frcp_rn expands to the 10-instruction IEEE division
     const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
     const float erf_abs = 1.0f - poly * e;                       // erf(|x| / sqrt 2)
     const float cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
