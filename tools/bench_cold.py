@@ -49,9 +49,18 @@ def main():
                                    ("text qkv fwd", L.NT, 5120, 2304, 768), ("text+vis-sized qkv", L.NT, 14592, 2304, 768),
                                    ("text+vis ffn-down", L.NT, 14592, 768, 3072), ("text+vis ffn-up", L.NT, 14592, 3072, 768)):
         fn, keep = make(layout, L.EPI_BF16, Mr, N, K, 1)
+        A, Bw = keep[0], keep[1]
+        A2, B2 = A.clone(), Bw.clone()
         res = [("itself", timed(fn, fn)), ("nothing (event gap)", timed(fn, nothing)), ("LayerNorm kernel", timed(fn, ln)),
                ("other GEMM template", timed(fn, other)), ("600 MB copy", timed(fn, flush)),
-               ("copy then itself", timed(fn, lambda: (flush(), fn())))]
+               ("copy then itself", timed(fn, lambda: (flush(), fn()))),
+               # what does the producer -> consumer hand-over of the step look like?  A freshly WRITTEN by another kernel / freshly READ
+               ("copy, then A rewritten", timed(fn, lambda: (flush(), A.copy_(A2)))),
+               ("copy, then A read", timed(fn, lambda: (flush(), A.float().sum()))),
+               ("copy, then A and B rewritten", timed(fn, lambda: (flush(), A.copy_(A2), Bw.copy_(B2)))),
+               ("copy, then B read", timed(fn, lambda: (flush(), Bw.float().sum()))),
+               ("copy, A rewritten, B read", timed(fn, lambda: (flush(), A.copy_(A2), Bw.view(torch.int32).sum()))),
+               ("copy, then B rewritten", timed(fn, lambda: (flush(), Bw.copy_(B2))))]
         print("%-20s M=%5d N=%4d K=%4d  " % (name, Mr, N, K) + "  ".join("%s: %.1f us" % r for r in res), flush=True)
 
 
