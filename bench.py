@@ -35,6 +35,7 @@ def parse():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (weak scaling)")
     ap.add_argument("--seq-len", type=int, default=20)
     ap.add_argument("--regions", type=int, default=36)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="arithmetic of the projection GEMMs (fp8: forward projections on the MX-scaled fp8 MFMA, bf16 elsewhere)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--serial", action="store_true", help="run the side-stream blocks (weight gradients) inline: per-kernel profiles without concurrency")
@@ -71,15 +72,17 @@ def _dev_int(addr, eng):
     raise KeyError(addr)
 
 
-def cpu_baseline(cfg_name, T, R, budget_s=25.0):
-    """fp32 oracle (the reference's arithmetic in stock torch CPU ops): forward + backward + AdamW, B = 32."""
+def cpu_baseline(cfg_name, T, R, budget_s=75.0):
+    """fp32 oracle (the reference's arithmetic in stock torch CPU ops): forward + backward + clip + AdamW, B = 32, on every
+    host core the process may use (count printed), SURVEY.md 8(d) protocol: 3 warm-up + 5 timed steps.  The time budget
+    only cuts the sample short on a slow host (the line then says how many steps were timed)."""
     from oracle import volta_ref as Rf
     try:
         ncpu = len(os.sched_getaffinity(0))
     except AttributeError:
         ncpu = os.cpu_count() or 1
-    torch.set_num_threads(max(1, min(ncpu, 16)))      # the GPU box grants a 16-CPU share per GPU
-    print("[bench] cpu baseline on %d threads" % torch.get_num_threads(), file=sys.stderr, flush=True)
+    torch.set_num_threads(max(1, ncpu))
+    print("[bench] cpu baseline on %d threads (os.cpu_count() = %s)" % (torch.get_num_threads(), os.cpu_count()), file=sys.stderr, flush=True)
     cfg = Rf.RefConfig.from_json_file(os.path.join(ROOT, "config", cfg_name + ".json"))
     sd = Rf.make_weights(cfg, seed=1, std=0.02)
     aliases = Rf.param_aliases(cfg)
@@ -89,11 +92,11 @@ def cpu_baseline(cfg_name, T, R, budget_s=25.0):
         full[a] = leaves[t]
     m = {k: torch.zeros_like(v) for k, v in leaves.items()}
     v2 = {k: torch.zeros_like(v) for k, v in leaves.items()}
-    B = 32
+    B, n_warm, n_timed = 32, 3, 5
     batch = Rf.synthetic_batch(cfg, B, T, R, seed=3)
     times = []
     t_start = time.time()
-    for step in range(1, 5):
+    for step in range(1, n_warm + n_timed + 1):
         t0 = time.time()
         lm, img, nsp = Rf.forward_from_batch(full, cfg, batch, train=True)
         for p in leaves.values():
@@ -108,16 +111,86 @@ def cpu_baseline(cfg_name, T, R, budget_s=25.0):
         print("[bench] cpu step %d: %.2f s" % (step, times[-1]), file=sys.stderr, flush=True)
         if time.time() - t_start > budget_s and len(times) >= 2:
             break
-    timed = times[1:] if len(times) > 1 else times
+    n_w = min(n_warm, len(times) - 1)
+    timed = times[n_w:]
     return dict(value=B * len(timed) / sum(timed), unit="image-text pairs/s", cores=torch.get_num_threads(), kind="port",
-                sample="%d timed steps (after 1 warm-up) of fwd+bwd+clip+AdamW, fp32 oracle, B=32, T=%d, R=%d, %s" % (len(timed), T, R, cfg_name))
+                sample="%d timed steps (after %d warm-up) of fwd+bwd+clip+AdamW, fp32 oracle, B=32, T=%d, R=%d, %s" % (len(timed), n_w, T, R, cfg_name))
+
+
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks through torch.distributed.run as a CHILD process (this
+    process has not touched the GPU yet -- never re-exec one that has) and hand its exit code back."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.call(cmd, env=env)
+
+
+def result_line(a, world, elapsed, t_issue, extra):
+    ms = elapsed * 1e3 / a.steps
+    pairs_s = a.batch * world * a.steps / elapsed
+    out = {"metric": "image-text pairs/sec, %s pretrain step" % a.config, "value": pairs_s, "unit": "image-text pairs/s",
+           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
+           "config": {"workload": "%s pretrain step (fwd+bwd+clip+AdamW%s), per-GPU batch %d, T=%d, %d regions (+1 global), objective 1, dropout on"
+                      % (a.config, "+allreduce" if world > 1 else "", a.batch, a.seq_len, a.regions),
+                      "global_batch": a.batch * world, "seq_len": a.seq_len, "regions": a.regions, "parallelism": "dp%d" % world},
+           "host_issue_ms_per_step": t_issue * 1e3 / a.steps}
+    out.update(extra)
+    return out, ms, pairs_s
+
+
+def dry_run(a, world, rank):
+    """VK_BENCH_DRY_RUN=1: the launcher / rendezvous / barrier / max-over-ranks / one-JSON-line plumbing of the N-rank
+    benchmark on CPU over gloo, with a small all-reduce standing in for the step.  A test of the harness, not a measurement."""
+    if world > 1:
+        dist.init_process_group("gloo")
+    buf = torch.ones(1024)
+
+    def step():
+        if world > 1:
+            dist.all_reduce(buf)
+            buf.mul_(1.0 / world)
+
+    for _ in range(a.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    t_issue = time.perf_counter() - t0
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed])
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t)
+    out, _, _ = result_line(a, world, elapsed, t_issue, {"dry_run": "harness rehearsal on CPU over gloo: no model step ran, the value means nothing"})
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
+    if os.environ.get("VK_BENCH_DRY_RUN") == "1":
+        return dry_run(a, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the HIP engine has no CPU path")
     # VK_BENCH_SHARED_GPU=1 is a REHEARSAL mode for the multi-rank code path on a one-GPU box: every rank uses cuda:0 and the
@@ -183,18 +256,10 @@ def main():
         t = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
-    ms = elapsed * 1e3 / a.steps
-    pairs_s = a.batch * world * a.steps / elapsed
     gflop = GFLOP_PER_PAIR.get((a.config, a.seq_len, a.regions))
-    out = {"metric": "image-text pairs/sec, %s pretrain step" % a.config, "value": pairs_s, "unit": "image-text pairs/s",
-           "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
-           "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": "%s pretrain step (fwd+bwd+clip+AdamW%s), per-GPU batch %d, T=%d, %d regions (+1 global), objective 1, dropout on"
-                      % (a.config, "+allreduce" if world > 1 else "", a.batch, a.seq_len, a.regions),
-                      "global_batch": a.batch * world, "seq_len": a.seq_len, "regions": a.regions, "parallelism": "dp%d" % world},
-           "host_issue_ms_per_step": t_issue * 1e3 / a.steps,
-           **({"rehearsal": "all ranks share cuda:0 over gloo: timings are meaningless"} if shared else {}),
-           "losses_last_step": [float(x.detach()) for x in losses]}
+    out, ms, pairs_s = result_line(a, world, elapsed, t_issue, {
+        **({"rehearsal": "all ranks share cuda:0 over gloo: timings are meaningless"} if shared else {}),
+        "losses_last_step": [float(x.detach()) for x in losses]})
     if rank == 0:
         print("[bench] timed region done: %.3f ms/step, %.1f pairs/s" % (ms, pairs_s), file=sys.stderr, flush=True)
         if gflop is not None:

@@ -148,6 +148,43 @@ def write_ctrl(BertConfig, Model):
         del model, sd
 
 
+def write_fullsize(BertConfig, Model):
+    """ctrl_vilbert_base at the BASELINE batch (B=256, T=20, R=36; forward only) and at B=32 (forward + backward): the
+    contract check of north_star's "loss matching reference to 1e-3 rel" at the size the bench line is quoted on, and
+    gradients at a batch where the ITM path's bf16 noise has averaged out.  Weights and batch come from the seed generators,
+    only losses, small slices, checksums and gradient norms / slices are stored (a few KB)."""
+    import json
+    name = "ctrl_vilbert_base"
+    cd = json.load(open(os.path.join(ROOT, "config", name + ".json")))
+    cfg = R.RefConfig(cd)
+    sd = R.make_weights(cfg, seed=3, std=0.03)
+    for B, want_grads in ((32, True), (256, False)):
+        batch = R.synthetic_batch(cfg, B=B, T=20, R=36, seed=7)
+        with torch.set_grad_enabled(want_grads):
+            out, model = run_reference(BertConfig, Model, cd, sd, batch, want_grads=want_grads)
+        blob = {"B": np.array([B])}
+        for k in ("loss_lm", "loss_img", "loss_nsp", "grad_norm"):
+            if k in out:
+                blob["out::" + k] = out[k]
+        blob["out::pooled_t_slice"] = out["pooled_t"][:, :64]
+        blob["out::pooled_v_slice"] = out["pooled_v"][:, :64]
+        blob["out::seq_t_slice"] = out["seq_t"][::16, :, :64]
+        blob["out::seq_v_slice"] = out["seq_v"][::16, :8, :64]
+        blob["out::seq_t_sum"] = np.array([out["seq_t"].astype(np.float64).sum()])
+        blob["out::seq_v_sum"] = np.array([out["seq_v"].astype(np.float64).sum()])
+        blob["out::seq_t_abs"] = np.array([np.abs(out["seq_t"].astype(np.float64)).sum()])
+        blob["out::seq_v_abs"] = np.array([np.abs(out["seq_v"].astype(np.float64)).sum()])
+        for k in GRAD_KEYS[1:]:
+            if "grad::" + k in out:
+                g = out["grad::" + k]
+                blob["out::gradslice::" + k] = g.reshape(g.shape[0], -1)[:16, :64] if g.ndim > 1 else g[:64]
+                blob["out::gradnorm::" + k] = np.array([np.sqrt((g.astype(np.float64) ** 2).sum())])
+        path = os.path.join(OUT, "%s_b%d.npz" % (name, B))
+        np.savez_compressed(path, **blob)
+        print(name, "B", B, "losses", out["loss_lm"], out["loss_img"], out["loss_nsp"], os.path.getsize(path) // 1024, "KB", flush=True)
+        del model, out
+
+
 def write_hf_remap(BertConfig, Model):
     """What the reference's from_pretrained(..., from_hf=True) (volta/utils.py:458-498) makes of a HuggingFace-layout
     BERT checkpoint: per model key the checksum of the tensor that landed there + the loader's missing / unexpected lists."""
@@ -320,6 +357,8 @@ if __name__ == "__main__":
         write_tiny(BertConfig, Model)
     if which in ("all", "ctrl"):
         write_ctrl(BertConfig, Model)
+    if which in ("all", "full"):
+        write_fullsize(BertConfig, Model)
     if which in ("all", "hf"):
         write_hf_remap(BertConfig, Model)
     if which in ("all", "tasks"):

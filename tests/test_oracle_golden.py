@@ -80,6 +80,22 @@ def test_ctrl_full_width_forward(golden_dir, name):
     np.testing.assert_allclose(taps["pooled_t"].numpy(), z["out::pooled_t"], atol=2e-4)
 
 
+def test_ctrl_vilbert_b32_forward_matches_reference(golden_dir):
+    """The oracle at a real batch (B=32, the cpu_baseline's own sample size) against the reference's fixture."""
+    z = load(golden_dir, "ctrl_vilbert_base_b32")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = R.RefConfig.from_json_file(os.path.join(root, "config", "ctrl_vilbert_base.json"))
+    sd = R.make_weights(cfg, seed=3, std=0.03)
+    batch = R.synthetic_batch(cfg, B=32, T=20, R=36, seed=7)
+    taps = {}
+    with torch.no_grad():
+        lm, img, nsp = R.forward_from_batch(sd, cfg, batch, taps=taps)
+    for got, key in ((lm, "loss_lm"), (img, "loss_img"), (nsp, "loss_nsp")):
+        np.testing.assert_allclose(got.numpy(), z["out::" + key], rtol=1e-5)
+    np.testing.assert_allclose(taps["seq_t"].numpy()[::16, :, :64], z["out::seq_t_slice"], atol=2e-4)
+    np.testing.assert_allclose(taps["pooled_v"].numpy()[:, :64], z["out::pooled_v_slice"], atol=2e-4)
+
+
 def test_single_stream_equals_vanilla_bert_on_concatenated_sequence():
     """SURVEY 8a': shared + single_ln sub-layers are plain BERT layers over cat(text, vision)."""
     cd = dict(vocab_size=50, hidden_size=32, num_attention_heads=4, intermediate_size=64, pooler_size=16, v_pooler_size=16,
