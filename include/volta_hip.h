@@ -286,9 +286,16 @@ int vk_mask_prep(const int64_t* mask, float* out, int n, vk_stream_t s);
  * package pinned at 1.1.0 in requirements.txt:39, not vendored):
  *   m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= lr_c * step_mult * m / (sqrt(v) + eps) ; p -= lr_c * wd_c * p
  * with g pre-multiplied by grad_scale * clip[1]; step_mult = sqrt(1-b2^t)/(1-b1^t) (correct_bias) or 1.
- * Arena length is a multiple of 1024; chunk_class[i] selects (lr multiplier, weight decay) of chunk i. */
+ * Arena length is a multiple of 1024; chunk_class[i] selects (lr multiplier, weight decay) of chunk i.  Class
+ * VK_CHUNK_SKIP marks chunks that take no part: frozen parameters (config.fixed_layers, volta/train_utils.py:250-255;
+ * the driver builds its groups from requires_grad parameters only, train_concap.py:200,213) and parameters without a
+ * gradient this step -- pytorch_transformers' AdamW skips `p.grad is None`, torch's clip_grad_norm_ likewise: no moment
+ * update, no decay, left out of the norm. */
+#define VK_CHUNK_SKIP 255
 int vk_grad_norm_workspace_floats(void);
 int vk_grad_norm_clip(const float* g, int64_t n, float pre_scale, float max_norm, float* partial, float* out, vk_stream_t s);
+/* same, leaving out the 1024-element chunks whose chunk_class is VK_CHUNK_SKIP (chunk_class NULL: all chunks) */
+int vk_grad_norm_clip_masked(const float* g, int64_t n, const uint8_t* chunk_class, float pre_scale, float max_norm, float* partial, float* out, vk_stream_t s);
 typedef struct vk_adamw_args {
     float* p;
     const float* g;
@@ -298,7 +305,7 @@ typedef struct vk_adamw_args {
     const uint8_t* chunk_class; /* [n / 1024] or NULL (class 0) */
     const float* clip;          /* device float[2] from vk_grad_norm_clip or NULL */
     int64_t n;
-    float cls_lr_mult[8];
+    float cls_lr_mult[8];       /* classes 0..7; chunks of class VK_CHUNK_SKIP are not touched */
     float cls_wd[8];
     float lr, beta1, beta2, eps, step_mult, grad_scale;
 } vk_adamw_args;

@@ -12,7 +12,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, cap):
+def _worker(rank, world, port, cap, mode="allreduce", wire="fp32", pad_to=1):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -23,10 +23,16 @@ def _worker(rank, world, port, cap):
     for it in range(3):
         for name, (o, n) in spans.items():
             flat[o:o + n] = (rank + 1) * (it + 1) * (1 + o % 7)        # closed form: mean = (world+1)/2 * ...
-        red = BucketReducer(flat)
-        for stage, ranges in plan_buckets(spans, ready, 4, cap):
+        red = BucketReducer(flat, mode=mode, wire=wire)
+        plan = plan_buckets(spans, ready, 4, cap, pad_to=pad_to, total=flat.numel())
+        covered = sorted(r for _, rs in plan for r in rs)
+        assert all(a[1] <= b[0] for a, b in zip(covered, covered[1:])), covered        # every element reduced at most once
+        if pad_to > 1 and cap >= 1 << 30:
+            assert len(covered) == 1, covered        # padded slots coalesce: the whole arena is ONE collective
+        for stage, ranges in plan:
             red.reduce(ranges)
         red.finish()
+        assert red.bytes_on_wire > 0
         for name, (o, n) in spans.items():
             want = (world + 1) / 2.0 * (it + 1) * (1 + o % 7)
             assert torch.allclose(flat[o:o + n], torch.full((n,), want)), (name, it, float(flat[o]), want)
@@ -48,3 +54,10 @@ def _free_port():
 def test_bucket_reducer_world2_gloo():
     for cap in (1, 4 * 5000, 1 << 30):
         mp.spawn(_worker, args=(2, _free_port(), cap), nprocs=2, join=True)
+
+
+def test_bucket_reducer_modes_world2_gloo():
+    """reduce-scatter + all-gather, the bf16 wire (fp32 sum) and slot-padded buckets give the same closed-form means."""
+    for mode, wire in (("rs_ag", "fp32"), ("allreduce", "bf16"), ("rs_ag", "bf16")):
+        for cap, pad_to in ((1, 1), (4 * 5000, 1024), (1 << 30, 1024)):
+            mp.spawn(_worker, args=(2, _free_port(), cap, mode, wire, pad_to), nprocs=2, join=True)

@@ -45,4 +45,107 @@ def test_adamw_clip_schedule_match_oracle():
         assert worst < 2e-6, (step, worst)
         sh = model._arena.view(named[3][0], "shadow").float().cpu()
         assert torch.equal(sh, op[named[3][0]].bfloat16().float()) or float((sh - op[named[3][0]]).abs().max()) < 1e-2
-    assert model._arena.shadow_version == model._arena.master._version
+    assert model._arena.shadow_version == model._arena.param_version()
+
+
+def _args(rcfg, seed=7, B=4):
+    from oracle import volta_ref as R
+    cb = {k: v.cuda() for k, v in R.synthetic_batch(rcfg, B, 20, 36, seed=seed).items()}
+    return (cb["input_ids"], cb["image_feat"], cb["image_loc"], cb["segment_ids"], cb["input_mask"], cb["image_mask"],
+            cb["lm_label_ids"], cb["image_label"], cb["image_cls"], None, None, None, None, None, cb["is_match"])
+
+
+def _same(a, b, tol=2e-6):
+    return all(abs(x - y) <= tol * max(abs(y), 1.0) for x, y in zip(a, b))
+
+
+def _build(name="gated", seed=2):
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_engine_gpu import build
+    return build(name, seed=seed)
+
+
+def test_bf16_weight_copies_follow_load_state_dict_and_torch_optimizers():
+    """The GEMMs read a bf16 shadow of the fp32 parameters.  Whatever writes the parameters through torch after the first
+    forward -- load_state_dict, a stock torch optimizer, a manual re-initialisation -- must be seen by the next forward."""
+    model, rcfg, sd = _build()
+    model.eval()
+    args = _args(rcfg)
+    with torch.no_grad():
+        first = [float(x) for x in model(*args)]
+        other, _, sd2 = _build(seed=5)
+        model.load_state_dict(sd2, strict=True)                   # after the arena exists and the shadow was built
+        got = [float(x) for x in model(*args)]
+        want = [float(x) for x in other.eval()(*args)]
+    assert _same(got, want) and not _same(got, first, 1e-3), (first, got, want)
+    # a stock torch optimizer on model.parameters(): the next forward must use the updated weights
+    model.train()
+    model.set_dropout_seed(3)
+    opt = torch.optim.SGD(model.parameters(), lr=0.5)
+    sum(model(*args)).sum().backward()
+    opt.step()
+    opt.zero_grad(set_to_none=True)
+    model.eval()
+    with torch.no_grad():
+        after = [float(x) for x in model(*args)]
+        fresh, _, _ = _build(seed=5)
+        fresh.load_state_dict({k: v.detach().cpu() for k, v in model.state_dict().items()}, strict=True)
+        want = [float(x) for x in fresh.cuda().eval()(*args)]
+    assert _same(after, want) and not _same(after, got, 1e-3), (got, after, want)
+    # in-place edits through .data bypass every version counter: the documented escape hatch
+    with torch.no_grad():
+        for p in model.parameters():
+            p.data.mul_(0.5)
+        model._arena.invalidate_shadow()
+        halved = [float(x) for x in model(*args)]
+    assert not _same(halved, after, 1e-3)
+
+
+def test_frozen_and_gradient_less_parameters_are_skipped():
+    """config.fixed_layers / freeze_layers (volta/train_utils.py:250-255): frozen parameters get no .grad, are left out of the
+    clipping norm and are not touched by AdamW (no decay either) -- pytorch_transformers' `if p.grad is None: continue`."""
+    from volta_amd.optimization import AdamW, clip_grad_norm_
+    model, rcfg, sd = _build()
+    model.train()
+    model.set_dropout_seed(11)
+    frozen = [n for n, _ in model.named_parameters() if n.startswith("bert.encoder.layer.0.") or n.startswith("bert.embeddings.")]
+    assert frozen
+    for n, p in model.named_parameters():
+        p.requires_grad_(n not in frozen)
+    model.materialize()
+    before = {n: p.detach().clone() for n, p in model.named_parameters()}
+    trainable = [(n, p) for n, p in model.named_parameters() if p.requires_grad]
+    opt = AdamW([{"params": [p], "weight_decay": 0.01} for _, p in trainable], lr=1e-3)
+    args = _args(rcfg)
+    sum(model(*args)).sum().backward()
+    named = dict(model.named_parameters())
+    assert all(named[n].grad is None for n in frozen) and all(p.grad is not None for _, p in trainable)
+    total = clip_grad_norm_(model.parameters(), 1e-3)            # tiny max-norm: the clip engages
+    want = torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in trainable))
+    assert abs(float(total) - float(want)) <= 1e-4 * float(want)
+    assert abs(float(torch.sqrt(sum((p.grad.double() ** 2).sum() for _, p in trainable))) - 1e-3) <= 1e-5     # clipped in place, frozen chunks untouched
+    opt.step()
+    torch.cuda.synchronize()
+    for n, p in model.named_parameters():
+        if n in frozen:
+            assert torch.equal(p.detach(), before[n]), n
+        else:
+            assert not torch.equal(p.detach(), before[n]), n
+    # a trainable parameter without a gradient this step is skipped too, and a later step picks it up again
+    opt.zero_grad()
+    sum(model(*args)).sum().backward()
+    victim_n, victim = trainable[-1]
+    snap, vgrad = victim.detach().clone(), victim.grad
+    victim.grad = None
+    opt.step()
+    torch.cuda.synchronize()
+    assert torch.equal(victim.detach(), snap)
+    victim.grad = vgrad
+    opt.step()
+    torch.cuda.synchronize()
+    assert not torch.equal(victim.detach(), snap)
+    # a foreign tensor in .grad is refused instead of silently stepping with the arena's stale gradient
+    victim.grad = torch.zeros_like(victim)
+    with pytest.raises(RuntimeError):
+        opt.step()

@@ -23,6 +23,7 @@ lib = C.CDLL(LIB_PATH)
 
 c_p = C.c_void_p
 i32 = C.c_int32
+CHUNK_SKIP = 255          # VK_CHUNK_SKIP
 
 
 class Dropout(C.Structure):
@@ -166,6 +167,7 @@ _sig("vk_mul_bf16", C.c_int, c_p, c_p, c_p, C.c_int64, c_p, C.c_int, c_p)
 _sig("vk_grad_norm_workspace_floats", C.c_int)
 _sig("vk_grad_norm_clip", C.c_int, c_p, C.c_int64, C.c_float, C.c_float, c_p, c_p, c_p)
 _sig("vk_adamw_step", C.c_int, C.POINTER(AdamwArgs), c_p)
+_sig("vk_grad_norm_clip_masked", C.c_int, c_p, C.c_int64, c_p, C.c_float, C.c_float, c_p, c_p, c_p)
 _sig("vk_axpy_f32", C.c_int, c_p, c_p, C.c_float, C.c_int64, c_p)
 _sig("vk_sum_slabs_f32", C.c_int, c_p, c_p, C.c_int64, C.c_int, C.c_int64, c_p)
 _sig("vk_sum_slabs_bf16", C.c_int, c_p, c_p, C.c_int64, C.c_int, C.c_int64, c_p, C.c_int, c_p)
@@ -185,7 +187,7 @@ EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_c
            "vk_add_dropout", "vk_colsum_bf16", "vk_vlbert_prep_fwd", "vk_vlbert_maskgrad", "vk_rowgroup_sum_bf16",
            "vk_relu_bwd_bf16", "vk_copy_async", "vk_select_rows", "vk_gather_rows", "vk_scatter_rows_add", "vk_xent_fwd",
            "vk_xent_bwd", "vk_kl_fwd", "vk_kl_bwd", "vk_loss_finalize", "vk_pool_mul_fwd", "vk_pool_mul_bwd",
-           "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_adamw_step",
+           "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_grad_norm_clip_masked", "vk_adamw_step",
            "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_enable", "vk_concap_batch"]
 
 

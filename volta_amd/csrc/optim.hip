@@ -14,10 +14,11 @@ namespace vk {
 
 constexpr int NORM_BLOCKS = 1024;
 
-__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* g, size_t n4, float* partial) {
+__global__ __launch_bounds__(256) void sqnorm_partial_kernel(const float* g, size_t n4, float* partial, const uint8_t* chunk_class) {
     __shared__ float sh[4];
     float s = 0.f;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        if (chunk_class && chunk_class[i >> 8] == VK_CHUNK_SKIP) continue;      // 256 float4 per 1024-element chunk
         const f32x4 v = *(const f32x4*)(g + i * 4);
         s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
     }
@@ -46,6 +47,7 @@ __global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* partial,
 __global__ __launch_bounds__(256) void adamw_kernel(vk_adamw_args a) {
     const size_t chunk = blockIdx.x;
     const int cls = a.chunk_class ? a.chunk_class[chunk] : 0;
+    if (cls == VK_CHUNK_SKIP) return;        // frozen / gradient-less parameters: weights, moments and the bf16 copy stay as they are
     const float lr = a.lr * a.cls_lr_mult[cls], wd = a.cls_wd[cls];
     const float gs = a.grad_scale * (a.clip ? a.clip[1] : 1.f);
     const size_t i = chunk * 1024 + threadIdx.x * 4;
@@ -132,12 +134,17 @@ extern "C" int vk_sum_slabs_f32(float* dst, const float* src, int64_t slab_strid
 
 extern "C" int vk_grad_norm_workspace_floats(void) { return NORM_BLOCKS; }
 
-extern "C" int vk_grad_norm_clip(const float* g, int64_t n, float pre_scale, float max_norm, float* partial, float* out, vk_stream_t s) {
+extern "C" int vk_grad_norm_clip_masked(const float* g, int64_t n, const uint8_t* chunk_class, float pre_scale, float max_norm, float* partial, float* out, vk_stream_t s) {
     if (n % 4 || ((uintptr_t)g & 15)) return set_error("vk_grad_norm_clip: n %% 4 == 0 and 16-byte alignment required");
+    if (chunk_class && (n % 1024)) return set_error("vk_grad_norm_clip_masked: a chunk mask needs an arena of whole 1024-element chunks");
     hipStream_t st = (hipStream_t)s;
-    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, st, g, (size_t)(n / 4), partial);
+    hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, st, g, (size_t)(n / 4), partial, chunk_class);
     hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, partial, NORM_BLOCKS, pre_scale, max_norm, out);
     return check_launch("vk_grad_norm_clip");
+}
+
+extern "C" int vk_grad_norm_clip(const float* g, int64_t n, float pre_scale, float max_norm, float* partial, float* out, vk_stream_t s) {
+    return vk_grad_norm_clip_masked(g, n, nullptr, pre_scale, max_norm, partial, out, s);
 }
 
 extern "C" int vk_adamw_step(const vk_adamw_args* a, vk_stream_t s) {

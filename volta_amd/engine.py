@@ -114,13 +114,26 @@ class ParamArena:
     def intact(self):
         return all(p.data_ptr() == self.master.data_ptr() + 4 * self.offset[n] for n, p in self.params.items())
 
+    def param_version(self):
+        """Sum of the parameters' own version counters.  Every Parameter was re-pointed with `p.data = view`, which gives
+        it a counter of ITS OWN: `load_state_dict`, `p.copy_()`, `p.add_()` (torch optimizers, EMA under no_grad) bump it
+        and leave `master._version` alone, so the base tensor's counter says nothing about them."""
+        return sum(p._version for p in self.params.values()) + self.master._version
+
     def refresh_shadow(self, force=False):
-        """bf16 copies of the weights; skipped when nothing wrote the master arena through torch since the
-        last refresh (the fused AdamW refreshes the shadow itself and does not bump the version)."""
-        v = self.master._version
-        if force or v != self.shadow_version:
+        """bf16 copies of the weights, rebuilt whenever a parameter was written through torch since the last refresh.
+        The fused AdamW refreshes the shadow inside its own launch and calls mark_shadow_fresh().  Not seen by any version
+        counter: in-place edits through `p.data` (`p.data.mul_()`): call invalidate_shadow() after those."""
+        v = self.param_version()
+        if force or self.shadow_version != v:
             check(L.lib.vk_cast_f32_bf16(ptr(self.master), ptr(self.shadow), self.total, L.stream_ptr()))
             self.shadow_version = v
+
+    def mark_shadow_fresh(self):
+        self.shadow_version = self.param_version()
+
+    def invalidate_shadow(self):
+        self.shadow_version = -1
 
 
 # ======================================================================================== plan

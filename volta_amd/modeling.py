@@ -349,8 +349,10 @@ class BertForVLPreTraining(PreTrainedModel):
         modules (`_torch_param_prefixes`) get their gradients from autograd (redirected into the arena by a hook)."""
         arena = eng.arena
         skip = getattr(self, "_torch_param_prefixes", ())
-        params = [(n, p) for n, p in arena.param_list() if not n.startswith(skip)] if skip else arena.param_list()
-        gviews = [g for (n, _), g in zip(arena.param_list(), arena.grad_views()) if not n.startswith(skip)] if skip else arena.grad_views()
+        # frozen parameters (requires_grad False: volta/train_utils.py:250-255) get no .grad, as under autograd; the
+        # optimizer and clip_grad_norm_ then leave their arena chunks alone
+        pairs = [((n, p), g) for (n, p), g in zip(arena.param_list(), arena.grad_views()) if p.requires_grad and not (skip and n.startswith(skip))]
+        params, gviews = [x[0] for x in pairs], [x[1] for x in pairs]
         n_have = sum(p.grad is not None for _, p in params)
         accumulate = n_have == len(params)
         if n_have and not accumulate:

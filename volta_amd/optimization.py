@@ -30,6 +30,28 @@ def _arena_of(params):
     return model, arena
 
 
+def _chunks_of(arena, name):
+    numel = 1
+    for d in arena.shape[name]:
+        numel *= d
+    return arena.offset[name] // 1024, (arena.offset[name] + numel + 1023) // 1024
+
+
+def _check_shared_chunks(arena, included, what, among=None):
+    """Skipping works on whole 1024-element chunks; only the fused Q|K|V slot packs several tensors into one chunk, and
+    those are frozen / trained together in every reference driver."""
+    inc, exc = set(), set()
+    for n in arena.params:
+        if among is not None and n not in among:
+            continue
+        c0, c1 = _chunks_of(arena, n)
+        (inc if n in included else exc).update(range(c0, c1))
+    both = inc & exc
+    if both:
+        raise RuntimeError("volta_amd: parameters sharing an arena chunk (the fused query / key / value slot) must all be %s or none "
+                           "of them (chunk %d)" % (what, min(both)))
+
+
 class AdamW(Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
         if lr < 0.0:
@@ -46,13 +68,12 @@ class AdamW(Optimizer):
     def _setup(self):
         allp = [p for g in self.param_groups for p in g["params"]]
         model, arena = _arena_of(allp)
-        opt_ptrs = {p.data_ptr() for p in allp}
-        if len(opt_ptrs) != len(arena.params):
-            raise RuntimeError("volta_amd.AdamW: pass every parameter of the model (frozen subsets are not supported yet)")
         byptr = {p.data_ptr(): n for n, p in arena.params.items()}
-        # classes: groups with identical (initial lr, wd, betas, eps, correct_bias) share one class
-        classes, cls_of_chunk = [], torch.zeros(arena.total // 1024, dtype=torch.uint8)
+        # classes: groups with identical (initial lr, wd, betas, eps, correct_bias) share one class; chunks of parameters the
+        # optimizer was not given (frozen: train_concap.py:200,213 builds its groups from requires_grad parameters) are skipped
+        classes, cls_of_chunk = [], torch.full((arena.total // 1024,), L.CHUNK_SKIP, dtype=torch.uint8)
         hyper = None
+        spans = []
         for g in self.param_groups:
             h = (tuple(g["betas"]), g["eps"], g["correct_bias"])
             hyper = hyper or h
@@ -66,14 +87,40 @@ class AdamW(Optimizer):
             ci = [c[0] for c in classes].index(key)
             for p in g["params"]:
                 n = byptr[p.data_ptr()]
-                numel = 1
-                for d in arena.shape[n]:
-                    numel *= d
-                c0 = arena.offset[n] // 1024
-                c1 = (arena.offset[n] + numel + 1023) // 1024
+                c0, c1 = _chunks_of(arena, n)
                 cls_of_chunk[c0:c1] = ci
-        self._fused = dict(model=model, arena=arena, classes=classes, chunk_class=cls_of_chunk.to(arena.device),
+                spans.append((p, n, c0, c1))
+        _check_shared_chunks(arena, {n for _, n, _, _ in spans}, "given to the optimizer")
+        self._fused = dict(model=model, arena=arena, classes=classes, base_class=cls_of_chunk, spans=spans, masks={},
+                           chunk_class=cls_of_chunk.to(arena.device),
                            m=torch.zeros_like(arena.master), v=torch.zeros_like(arena.master), step=0)
+
+    def _chunk_class_for_step(self):
+        """Parameters without a gradient this step are skipped like pytorch_transformers' AdamW does (`if p.grad is None:
+        continue`): no moment update, no decay, and never a stale gradient left in the arena by an earlier step."""
+        f = self._fused
+        arena = f["arena"]
+        missing = []
+        for i, (p, n, c0, c1) in enumerate(f["spans"]):
+            g = p.grad
+            if g is None:
+                missing.append(i)
+            elif g.data_ptr() != arena.grad.data_ptr() + 4 * arena.offset[n]:
+                raise RuntimeError("volta_amd.AdamW: the gradient of %s is not the engine's arena view (a foreign tensor was "
+                                   "assigned to .grad); run backward through the model, or zero_grad(set_to_none=True)" % n)
+        if not missing:
+            return f["chunk_class"]
+        key = tuple(missing)
+        if key not in f["masks"]:
+            if len(f["masks"]) > 16:
+                f["masks"].clear()
+            _check_shared_chunks(arena, {f["spans"][i][1] for i in range(len(f["spans"])) if i not in set(missing)}, "with a gradient this step",
+                                 among={sp[1] for sp in f["spans"]})
+            cc = f["base_class"].clone()
+            for i in missing:
+                cc[f["spans"][i][2]:f["spans"][i][3]] = L.CHUNK_SKIP
+            f["masks"][key] = cc.to(arena.device)
+        return f["masks"][key]
 
     @torch.no_grad()
     def step(self, closure=None, grad_scale=1.0):
@@ -87,7 +134,7 @@ class AdamW(Optimizer):
         b1, b2 = g0["betas"]
         a = L.AdamwArgs()
         a.p, a.g, a.m, a.v = arena.master.data_ptr(), arena.grad.data_ptr(), f["m"].data_ptr(), f["v"].data_ptr()
-        a.shadow, a.chunk_class = arena.shadow.data_ptr(), f["chunk_class"].data_ptr()
+        a.shadow, a.chunk_class = arena.shadow.data_ptr(), self._chunk_class_for_step().data_ptr()
         clip = getattr(arena, "pending_clip", None)
         a.clip = clip.data_ptr() if clip is not None else None
         arena.pending_clip = None
@@ -100,7 +147,7 @@ class AdamW(Optimizer):
         a.step_mult = math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t) if g0["correct_bias"] else 1.0
         a.grad_scale = grad_scale
         L.check(L.lib.vk_adamw_step(C.byref(a), L.stream_ptr()))
-        arena.shadow_version = arena.master._version      # the kernel refreshed the bf16 copies itself
+        arena.mark_shadow_fresh()      # the kernel refreshed the bf16 copies itself
         return loss
 
     # ---- checkpoint interchange (volta/train_utils.py:295-340 saves optimizer.state_dict() of pytorch_transformers'
@@ -177,24 +224,53 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, defer_to_optimizer=Fals
     if float(norm_type) != 2.0:
         raise NotImplementedError("only the L2 norm is supported")
     model = None
+    whole = False
     if inspect.isgenerator(parameters) and parameters.gi_code is torch.nn.Module.parameters.__code__ and parameters.gi_frame is not None:
         # `model.parameters()` of a volta_amd model, not started yet: the whole arena, no need to walk 600 tensors
         owner = parameters.gi_frame.f_locals.get("self")
         if getattr(owner, "_vk_is_model", False) and owner.__dict__.get("_arena") is not None:
             model, arena = owner, owner.materialize()
+            whole = True
     if model is None:
         params = [parameters] if isinstance(parameters, torch.Tensor) else list(parameters)
         model, arena = _arena_of(params)
-        if len(params) != len(arena.params):
-            raise RuntimeError("clip_grad_norm_: pass every parameter of the model (the norm is taken over the whole gradient arena)")
-    if not all(p.grad is g or (p.grad is not None and p.grad.data_ptr() == g.data_ptr()) for (_, p), g in zip(arena.param_list(), arena.grad_views())):
+        given = {p.data_ptr() for p in params}
+    # parameters without a gradient (frozen, or an unused head) are left out, as torch.nn.utils.clip_grad_norm_ does
+    plist, gviews = arena.param_list(), arena.grad_views()
+    have = []
+    for (n, p), g in zip(plist, gviews):
+        if not whole and p.data_ptr() not in given:
+            continue
+        if p.grad is None:
+            continue
+        if not (p.grad is g or p.grad.data_ptr() == g.data_ptr()):
+            raise RuntimeError("clip_grad_norm_: the gradient of %s is not attached to the engine's arena (run backward first)" % n)
+        have.append(n)
+    if not have:
         raise RuntimeError("clip_grad_norm_: gradients are not attached to the engine's arena (run backward first)")
+    mask = None
+    if len(have) != len(plist):
+        cache = arena.__dict__.setdefault("_clip_masks", {})
+        key = tuple(have)
+        if key not in cache:
+            if len(cache) > 16:
+                cache.clear()
+            _check_shared_chunks(arena, set(have), "part of the norm")
+            cc = torch.full((arena.total // 1024,), L.CHUNK_SKIP, dtype=torch.uint8)
+            for n in have:
+                c0, c1 = _chunks_of(arena, n)
+                cc[c0:c1] = 0
+            cache[key] = cc.to(arena.device)
+        mask = cache[key]
     if not hasattr(arena, "norm_ws"):
         arena.norm_ws = torch.empty(L.lib.vk_grad_norm_workspace_floats(), device=arena.device)
     out = torch.empty(2, device=arena.device)
-    L.check(L.lib.vk_grad_norm_clip(L.ptr(arena.grad), arena.total, pre_scale, float(max_norm), L.ptr(arena.norm_ws), L.ptr(out), L.stream_ptr()))
+    L.check(L.lib.vk_grad_norm_clip_masked(L.ptr(arena.grad), arena.total, L.ptr(mask), pre_scale, float(max_norm), L.ptr(arena.norm_ws), L.ptr(out), L.stream_ptr()))
     if defer_to_optimizer:
         arena.pending_clip = out
-    else:
+    elif mask is None:
         arena.grad.mul_(out[1])
+    else:
+        for n in have:
+            arena.view(n, "grad").mul_(out[1])
     return out[0]
