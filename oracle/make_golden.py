@@ -185,6 +185,32 @@ def write_fullsize(BertConfig, Model):
         del model, out
 
 
+def write_init_stats(BertConfig, Model):
+    """What the reference's CONSTRUCTOR leaves in every tensor of the five real ctrl_* models (encoders.py:904-915 normal / zero /
+    one init, :753-764 xavier heads, embeddings.py:229-238,328-334,428-431 family-specific copies and zero LayerNorm weights):
+    per state_dict key [mean, std, min, max] plus the groups of keys holding identical values (aliases and copy-initialised
+    tables).  Statistics, not values: the two code bases draw from the generator in different orders."""
+    import json
+    for name in ("ctrl_vilbert_base", "ctrl_lxmert", "ctrl_uniter_base", "ctrl_visualbert_base", "ctrl_vl-bert_base"):
+        cd = json.load(open(os.path.join(ROOT, "config", name + ".json")))
+        torch.manual_seed(1234)
+        model = Model(BertConfig.from_dict(cd))
+        sd = model.state_dict()
+        keys = list(sd.keys())
+        stats = np.array([[float(v.double().mean()), float(v.double().std(unbiased=False)), float(v.min()), float(v.max())] for v in sd.values()])
+        # groups of equal tensors among same-shaped, non-constant ones
+        sig = {}
+        for k, v in sd.items():
+            if float(v.double().std(unbiased=False)) > 0:
+                sig.setdefault((tuple(v.shape), float(v.double().sum()), float(v.reshape(-1)[0])), []).append(k)
+        groups = [g for g in sig.values() if len(g) > 1 and all(torch.equal(sd[g[0]], sd[k]) for k in g)]
+        path = os.path.join(OUT, "init_" + name + ".npz")
+        np.savez_compressed(path, keys=np.array(keys), stats=stats, shapes=np.array([json.dumps(list(v.shape)) for v in sd.values()]),
+                            equal_groups=np.array(json.dumps(groups)))
+        print("init", name, len(keys), "keys,", len(groups), "groups of equal tensors", os.path.getsize(path) // 1024, "KB", flush=True)
+        del model
+
+
 def write_hf_remap(BertConfig, Model):
     """What the reference's from_pretrained(..., from_hf=True) (volta/utils.py:458-498) makes of a HuggingFace-layout
     BERT checkpoint: per model key the checksum of the tensor that landed there + the loader's missing / unexpected lists."""
@@ -359,6 +385,8 @@ if __name__ == "__main__":
         write_ctrl(BertConfig, Model)
     if which in ("all", "full"):
         write_fullsize(BertConfig, Model)
+    if which in ("all", "init"):
+        write_init_stats(BertConfig, Model)
     if which in ("all", "hf"):
         write_hf_remap(BertConfig, Model)
     if which in ("all", "tasks"):

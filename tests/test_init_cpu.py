@@ -1,0 +1,52 @@
+"""what the model CONSTRUCTOR leaves in the parameters, against fixtures of the reference's own constructor
+(oracle/make_golden.py init; encoders.py:904-915 N(0, 0.02) / zeros / ones, :753-764 xavier-uniform heads, embeddings.py:229-238
+VL-BERT zero LayerNorm weights and mask embedding, :328-334 VisualBERT copied tables, :428-431 UNITER copied LayerNorm).  The two
+code bases consume the generator in different orders, so values are compared through per-tensor statistics (exactly for constant
+tensors, within sampling error otherwise) and through the groups of tensors that must hold IDENTICAL values."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CTRL = ["ctrl_vilbert_base", "ctrl_lxmert", "ctrl_uniter_base", "ctrl_visualbert_base", "ctrl_vl-bert_base"]
+
+
+@pytest.mark.parametrize("name", CTRL)
+def test_constructor_init_matches_reference_statistics(golden_dir, name):
+    from volta_amd.config import BertConfig
+    from volta_amd.modeling import BertForVLPreTraining
+    z = np.load(os.path.join(golden_dir, "init_" + name + ".npz"))
+    torch.manual_seed(99)
+    model = BertForVLPreTraining(BertConfig.from_json_file(os.path.join(ROOT, "config", name + ".json")))
+    sd = model.state_dict()
+    keys = [str(k) for k in z["keys"]]
+    assert list(sd.keys()) == keys
+    bad = []
+    for k, (mean, std, lo, hi), shape in zip(keys, z["stats"], z["shapes"]):
+        v = sd[k].double()
+        assert list(v.shape) == json.loads(str(shape)), k
+        n = v.numel()
+        m, s = float(v.mean()), float(v.std(unbiased=False))
+        if std == 0.0:                                  # constant tensors: zeros, ones, zero-initialised LayerNorm weights
+            if s != 0.0 or m != mean:
+                bad.append((k, "constant", m, mean))
+            continue
+        # random tensors: the mean within 6 standard errors (two independent draws), the spread within 6 sigma of its own
+        # sampling error (uniform and normal alike: Var(s) <= s^2 / n for both), the support for the uniform ones
+        if abs(m - mean) > 6.0 * std * np.sqrt(2.0 / n) + 1e-12:
+            bad.append((k, "mean", m, mean))
+        if abs(s - std) > 6.0 * std * np.sqrt(1.0 / n) + 1e-12:
+            bad.append((k, "std", s, std))
+        uniform = abs(hi + lo) < 0.05 * hi and abs(hi / std - np.sqrt(3.0)) < 0.05      # xavier-uniform: max = sqrt(3) sigma
+        if uniform and not (float(v.max()) <= hi * 1.02 and float(v.min()) >= lo * 1.02 and float(v.max()) > hi * 0.9):
+            bad.append((k, "uniform support", float(v.min()), float(v.max()), lo, hi))
+        if not uniform and n > 10000 and not (3.0 < float(v.abs().max()) / s < 7.0):     # a normal tensor has 3-7 sigma extremes at these sizes
+            bad.append((k, "normal tails", float(v.abs().max()) / s))
+    assert not bad, bad[:10]
+    # tensors the reference initialises as copies of one another (and aliases) hold identical values here too
+    for group in json.loads(str(z["equal_groups"])):
+        for k in group[1:]:
+            assert torch.equal(sd[group[0]], sd[k]), (group[0], k)

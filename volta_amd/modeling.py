@@ -216,6 +216,7 @@ class BertPreTrainingHeads(M.Holder):
         self.add_module("imagePredictions", img)
         self.fusion_method = config.fusion_method
         M.init_heads_(self)
+        M.init_tied_decoder_(bert_model_embedding_weights)
 
 
 class _PretrainStep(torch.autograd.Function):

@@ -209,8 +209,30 @@ def init_heads_(module):
             m.bias.data.zero_()
 
 
+def torch_default_init_(module):
+    """What torch's own constructors leave in nn.Embedding (N(0, 1)) and nn.Linear (weight and bias uniform in
+    +-1 / sqrt(fan_in): kaiming_uniform_(a = sqrt 5))."""
+    for m in module.modules():
+        if isinstance(m, TableParams):
+            m.weight.data.normal_(mean=0.0, std=1.0)
+        elif isinstance(m, LinearParams):
+            bound = 1.0 / math.sqrt(m.in_features)
+            m.weight.data.uniform_(-bound, bound)
+            m.bias.data.uniform_(-bound, bound)
+        elif isinstance(m, LayerNormParams):
+            m.weight.data.fill_(1.0)
+            m.bias.data.zero_()
+
+
 def special_init_embeddings_(emb, kind, cfg):
-    """Family-specific initial values (embeddings.py:229-238, 328-334, 428-431)."""
+    """Family-specific initial values.  The reference builds the SHARED (single-stream) embedding modules AFTER
+    `BertModel.apply(init_weights)` has run (encoders.py:949-952) and never re-applies it, so their tensors keep torch's
+    constructor defaults -- tables N(0, 1) with a zero padding row, linears uniform +-1/sqrt(fan_in) incl. the bias --
+    except what their own constructors set (embeddings.py:229-238, 328-334, 428-431).  Kept: the oracle is the truth."""
+    if kind not in SHARED:
+        return
+    torch_default_init_(emb)
+    emb.word_embeddings.weight.data[0].zero_()              # padding_idx = 0 (embeddings.py:207,313,410)
     if kind == "visualbert":
         emb.token_type_embeddings_visual.weight = nn.Parameter(copy.deepcopy(emb.token_type_embeddings.weight.data))
         emb.position_embeddings_visual.weight = nn.Parameter(copy.deepcopy(emb.position_embeddings.weight.data))
@@ -220,11 +242,17 @@ def special_init_embeddings_(emb, kind, cfg):
     elif kind == "vl-bert":
         lin = emb.obj_downsample._modules["1"]
         bound = math.sqrt(6.0 / (lin.in_features + lin.out_features))
-        lin.weight.data.uniform_(-bound, bound)
-        lin.bias.data.zero_()
+        lin.weight.data.uniform_(-bound, bound)              # xavier; the bias keeps the constructor default
         emb.object_mask_visual_embedding.weight.data.fill_(0.0)
         emb.object_linguistic_embeddings.weight.data.normal_(mean=0.0, std=cfg.initializer_range)
-        for t in ("end_embedding", "word_embeddings", "position_embeddings", "token_type_embeddings"):
-            getattr(emb, t).weight.data.normal_(mean=0.0, std=0.02)
+        if hasattr(emb, "object_mask_word_embedding"):
+            emb.object_mask_word_embedding.weight.data.normal_(mean=0.0, std=cfg.initializer_range)
         emb.visual_ln_text.weight.data.fill_(0.0)
         emb.visual_ln_object.weight.data.fill_(0.0)
+
+
+def init_tied_decoder_(weight):
+    """The LM decoder is an nn.Linear(hidden, vocab) whose weight IS the word-embedding table (encoders.py:688-691), and the
+    heads' init (encoders.py:753-764) xavier-initialises every nn.Linear: the table ends up uniform in +-sqrt(6 / (V + H))."""
+    bound = math.sqrt(6.0 / (weight.shape[0] + weight.shape[1]))
+    weight.data.uniform_(-bound, bound)
