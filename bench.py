@@ -72,17 +72,45 @@ def _dev_int(addr, eng):
     raise KeyError(addr)
 
 
+def usable_cpus():
+    """Host cores this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box shows all 256 host
+    cores to a container that is granted a 16-CPU share; 256 torch threads on 16 CPUs run ~50x slower than 16)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as fh:                       # cgroup v2: "<quota> <period>" or "max <period>"
+            q, per = fh.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as fq, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fp:      # cgroup v1
+                q, per = float(fq.read()), float(fp.read())
+                if q > 0:
+                    quota = q / per
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota + 0.5)))
+    elif n > 64:
+        n = 16        # a whole host's cores visible and no quota readable: assume the pool's documented 16-CPU share per GPU
+    cap = os.environ.get("VK_BENCH_CPU_THREADS")
+    if cap:
+        n = min(n, int(cap))
+    return max(1, n)
+
+
 def cpu_baseline(cfg_name, T, R, budget_s=75.0):
     """fp32 oracle (the reference's arithmetic in stock torch CPU ops): forward + backward + clip + AdamW, B = 32, on every
     host core the process may use (count printed), SURVEY.md 8(d) protocol: 3 warm-up + 5 timed steps.  The time budget
     only cuts the sample short on a slow host (the line then says how many steps were timed)."""
     from oracle import volta_ref as Rf
-    try:
-        ncpu = len(os.sched_getaffinity(0))
-    except AttributeError:
-        ncpu = os.cpu_count() or 1
+    ncpu = usable_cpus()
     torch.set_num_threads(max(1, ncpu))
-    print("[bench] cpu baseline on %d threads (os.cpu_count() = %s)" % (torch.get_num_threads(), os.cpu_count()), file=sys.stderr, flush=True)
+    print("[bench] cpu baseline on %d threads (os.cpu_count() = %s, usable = %d)" % (torch.get_num_threads(), os.cpu_count(), ncpu), file=sys.stderr, flush=True)
     cfg = Rf.RefConfig.from_json_file(os.path.join(ROOT, "config", cfg_name + ".json"))
     sd = Rf.make_weights(cfg, seed=1, std=0.02)
     aliases = Rf.param_aliases(cfg)

@@ -77,6 +77,12 @@ typedef struct vk_gemm_problem {
 #define VK_GEMM_MAX_GROUP 32
 /* One launch for up to VK_GEMM_MAX_GROUP independent problems of the same layout / epilogue. */
 int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, vk_stream_t s);
+/* Same with the tile geometry chosen by the caller instead of the shape heuristic (0 = heuristic): 128 (128 x 128 tiles, 4 waves),
+ * 258 / 259 / 260 (256 x 256 / 192 / 128 tiles, 8 waves, LDS-DMA ring), optionally OR-ed with VK_GEMM_PERSISTENT (one workgroup per CU
+ * walks the tile list; NT / NN without `dyn`) or VK_GEMM_ONE_TILE_PER_WG.  A per-call argument, no library state: re-entrant. */
+#define VK_GEMM_PERSISTENT 0x1000
+#define VK_GEMM_ONE_TILE_PER_WG 0x2000
+int vk_gemm_grouped_ex(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, int geometry, vk_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * Fused (dropout +) residual + LayerNorm.  Replaces apex FusedLayerNormAffineFunction
@@ -317,6 +323,21 @@ int vk_sum_slabs_f32(float* dst, const float* src, int64_t slab_stride, int nsla
 /* Same with a bf16 destination and a device-side row count: rows = min(*dyn_rows, n / row_len) rows of row_len. */
 int vk_sum_slabs_bf16(void* dst, const float* src, int64_t slab_stride, int nslabs, int64_t n, const int32_t* dyn_rows, int row_len, vk_stream_t s);
 int vk_memset_async(void* p, int value, int64_t bytes, vk_stream_t s);
+/* The tail of a sub-layer's weight-gradient block in ONE launch: every split-K slab sum (kind 0, as vk_sum_slabs_f32) and every
+ * deferred LayerNorm dgamma / dbeta column reduction (kind 1, as vk_ln_bwd_finalize) of the sub-layer.  The reference has no
+ * counterpart (autograd accumulates each of these tensors with its own kernels); njobs <= VK_TAIL_MAX_JOBS. */
+#define VK_TAIL_MAX_JOBS 16
+typedef struct vk_tail_job {
+    float* dst;             /* kind 0: destination [n]; kind 1: dgamma [H] */
+    float* dst2;            /* kind 1: dbeta [H] */
+    const float* src;       /* kind 0: slabs, slab s at src + s * stride; kind 1: partial records [rows][2][H] */
+    int64_t stride;         /* kind 0: elements between slabs (multiple of 4) */
+    int64_t n;              /* kind 0: elements; kind 1: H */
+    int32_t kind, count;    /* count: slabs (kind 0) / partial records (kind 1) */
+    int32_t accumulate;     /* kind 1: dgamma / dbeta += */
+    int32_t block_start;    /* filled by vk_side_tail */
+} vk_tail_job;
+int vk_side_tail(const vk_tail_job* jobs, int njobs, vk_stream_t s);
 
 /* out[i] = a[i] * b[i] (bf16); processes rows * row_len elements where rows = min(*dyn_rows, n / row_len)
  * when dyn_rows != NULL.  (d gelu(u) = dz * gelu'(u) in the prediction-head transforms.) */
@@ -346,7 +367,8 @@ enum {
 enum {
     VK_FN_CAST = 1, VK_FN_MEMSET, VK_FN_LOC_FWD, VK_FN_LOC_BWD, VK_FN_ADD_DROPOUT, VK_FN_COLSUM, VK_FN_SELECT,
     VK_FN_GATHER, VK_FN_SCATTER_ADD, VK_FN_LOSS_FINAL, VK_FN_POOL_FWD, VK_FN_POOL_BWD, VK_FN_MASK_PREP, VK_FN_MUL,
-    VK_FN_VLBERT_PREP, VK_FN_VLBERT_MASKGRAD, VK_FN_ROWGROUP_SUM, VK_FN_RELU_BWD, VK_FN_COPY, VK_FN_SUM_SLABS, VK_FN_SUM_SLABS_BF16
+    VK_FN_VLBERT_PREP, VK_FN_VLBERT_MASKGRAD, VK_FN_ROWGROUP_SUM, VK_FN_RELU_BWD, VK_FN_COPY, VK_FN_SUM_SLABS, VK_FN_SUM_SLABS_BF16,
+    VK_FN_SIDE_TAIL      /* p[0] = vk_tail_job[n[0]] */
 };
 typedef struct vk_generic_args {   /* positional arguments of the small entry points, see executor.cpp */
     int32_t fn;

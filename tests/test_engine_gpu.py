@@ -97,7 +97,7 @@ def _parity(name, train, B, T, Rn, batch_seed=7):
         tol = 1e-2 if nm == "nsp" else 1e-3
         assert abs(g - r) <= tol * max(abs(r), 1e-3) + 1e-4, (name, nm, g, r)
     tot, rtot = float((lm + img + nsp).detach()), float((olm + oimg + onsp).detach())
-    assert abs(tot - rtot) <= 1e-3 * abs(rtot), (name, "total loss", tot, rtot)
+    assert abs(tot - rtot) <= 1e-3 * abs(rtot) + 1e-2 * abs(float(onsp.detach())), (name, "total loss", tot, rtot)     # 1e-3 + the B = 4 ITM allowance
     # ---- gradients of every parameter: once for the MLM + region losses, once for the ITM loss (whose
     # gradient flows through B x 2 logits only, so the forward bf16 noise shows up as a common scale error)
     named = dict(model.named_parameters())

@@ -10,15 +10,17 @@ def _mods():
     return L, ops
 
 
-@pytest.fixture(params=[0, 128, 256, 258, 259, 260], ids=["auto", "tile128x128", "tile256x256", "tile256x256k32", "tile256x192k32", "tile256x128k32"], autouse=True)
+GEOMETRIES = {"auto": 0, "tile128x128": 128, "tile256x256": 258, "tile256x192": 259, "tile256x128": 260,
+              "tile256x256_persistent": 258 | 0x1000, "tile256x192_persistent": 259 | 0x1000}
+
+
+@pytest.fixture(params=list(GEOMETRIES.values()), ids=list(GEOMETRIES), autouse=True)
 def tile_edge(request):
-    """Every GEMM test runs under the tile heuristic and with each tile geometry forced."""
-    import ctypes
-    from volta_amd import _lib as L
-    L.lib.vk_gemm_set_tile.argtypes = [ctypes.c_int]
-    L.lib.vk_gemm_set_tile(request.param)
+    """Every GEMM test runs under the tile heuristic and with each tile geometry named explicitly (vk_gemm_grouped_ex)."""
+    from volta_amd import ops
+    ops.default_geometry = request.param
     yield request.param
-    L.lib.vk_gemm_set_tile(0)
+    ops.default_geometry = 0
 
 
 def rnd(shape, g, scale=1.0):

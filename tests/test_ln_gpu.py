@@ -53,3 +53,25 @@ def test_ln_fwd_bwd(M, H, mode):
     tol = 2e-2 * max(1.0, float(gm.grad.abs().max()))
     np.testing.assert_allclose(dgam.cpu().numpy(), gm.grad.numpy(), atol=tol)
     np.testing.assert_allclose(dbet.cpu().numpy(), bt.grad.numpy(), atol=tol)
+
+
+def test_side_tail_matches_separate_reductions():
+    """vk_side_tail (one launch for a sub-layer's slab sums and LayerNorm column reductions) against torch sums."""
+    import ctypes as C
+    from volta_amd import _lib as L
+    g = torch.Generator(device="cuda").manual_seed(0)
+    H, rows = 768, 57
+    slabs = torch.randn(3 * 1004, device="cuda", generator=g)           # 3 slabs of 1002 elements at stride 1004 (ragged tail of 2)
+    part = torch.randn(rows, 2, H, device="cuda", generator=g)
+    big = torch.randn(4, 70000, device="cuda", generator=g)
+    d0, d1 = torch.zeros(1002, device="cuda"), torch.zeros(70000, device="cuda")
+    dg, db = torch.ones(H, device="cuda"), torch.ones(H, device="cuda")
+    jobs = (L.TailJob * 3)(L.TailJob(d0.data_ptr(), None, slabs.data_ptr(), 1004, 1002, 0, 3, 0, 0),
+                           L.TailJob(dg.data_ptr(), db.data_ptr(), part.data_ptr(), 0, H, 1, rows, 1, 0),
+                           L.TailJob(d1.data_ptr(), None, big.data_ptr(), 70000, 70000, 0, 4, 0, 0))
+    L.check(L.lib.vk_side_tail(jobs, 3, L.stream_ptr()))
+    torch.cuda.synchronize()
+    want0 = sum(slabs[s * 1004:s * 1004 + 1002] for s in range(3))
+    assert torch.allclose(d0, want0, atol=1e-5)
+    assert torch.allclose(d1, big.sum(0), atol=1e-5)
+    assert torch.allclose(dg, 1.0 + part[:, 0].sum(0), atol=1e-4) and torch.allclose(db, 1.0 + part[:, 1].sum(0), atol=1e-4)

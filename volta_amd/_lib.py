@@ -7,7 +7,9 @@ import os
 import torch  # noqa: F401  -- must come first: libvolta_hip.so has to bind to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvolta_hip.so")
+# VK_LIB=study loads the measurement build (tools/ only: ablation switches, geometry overrides, the 4-phase study kernel)
+LIB_PATH = os.path.join(_HERE, "libvolta_hip_study.so" if os.environ.get("VK_LIB") == "study" else "libvolta_hip.so")
+GEMM_PERSISTENT, GEMM_ONE_TILE_PER_WG = 0x1000, 0x2000
 
 
 class VoltaHipError(RuntimeError):
@@ -93,6 +95,14 @@ class AdamwArgs(C.Structure):
                 ("grad_scale", C.c_float)]
 
 
+class TailJob(C.Structure):
+    _fields_ = [("dst", c_p), ("dst2", c_p), ("src", c_p), ("stride", C.c_int64), ("n", C.c_int64), ("kind", i32), ("count", i32),
+                ("accumulate", i32), ("block_start", i32)]
+
+
+TAIL_MAX_JOBS = 16
+
+
 class GenericArgs(C.Structure):
     _fields_ = [("fn", i32), ("p", c_p * 6), ("n", C.c_int64 * 6), ("f", C.c_float * 2), ("drop", Dropout)]
 
@@ -105,7 +115,7 @@ class Op(C.Structure):
  OP_KL_FWD, OP_KL_BWD, OP_GENERIC, OP_SIDE_BEGIN, OP_SIDE_END, OP_WAIT_SIDE, OP_JOIN, OP_LN_FINALIZE) = range(1, 18)
 (FN_CAST, FN_MEMSET, FN_LOC_FWD, FN_LOC_BWD, FN_ADD_DROPOUT, FN_COLSUM, FN_SELECT, FN_GATHER, FN_SCATTER_ADD,
  FN_LOSS_FINAL, FN_POOL_FWD, FN_POOL_BWD, FN_MASK_PREP, FN_MUL, FN_VLBERT_PREP, FN_VLBERT_MASKGRAD, FN_ROWGROUP_SUM,
- FN_RELU_BWD, FN_COPY, FN_SUM_SLABS, FN_SUM_SLABS_BF16) = range(1, 22)
+ FN_RELU_BWD, FN_COPY, FN_SUM_SLABS, FN_SUM_SLABS_BF16, FN_SIDE_TAIL) = range(1, 23)
 
 
 class AttnArgs(C.Structure):
@@ -135,6 +145,7 @@ _sig("vk_last_error", C.c_char_p)
 _sig("vk_set_seed", C.c_int, c_p, C.c_uint64, c_p)
 _sig("vk_cast_f32_bf16", C.c_int, c_p, c_p, C.c_int64, c_p)
 _sig("vk_gemm_grouped", C.c_int, C.c_int, C.c_int, C.POINTER(GemmProblem), C.c_int, c_p)
+_sig("vk_gemm_grouped_ex", C.c_int, C.c_int, C.c_int, C.POINTER(GemmProblem), C.c_int, C.c_int, c_p)
 _sig("vk_gated_attn_fwd", C.c_int, C.POINTER(AttnArgs), c_p)
 _sig("vk_gated_attn_bwd", C.c_int, C.POINTER(AttnArgs), C.POINTER(AttnBwdArgs), c_p)
 _sig("vk_ln_fwd", C.c_int, C.POINTER(LnArgs), c_p)
@@ -172,6 +183,7 @@ _sig("vk_axpy_f32", C.c_int, c_p, c_p, C.c_float, C.c_int64, c_p)
 _sig("vk_sum_slabs_f32", C.c_int, c_p, c_p, C.c_int64, C.c_int, C.c_int64, c_p)
 _sig("vk_sum_slabs_bf16", C.c_int, c_p, c_p, C.c_int64, C.c_int, C.c_int64, c_p, C.c_int, c_p)
 _sig("vk_memset_async", C.c_int, c_p, C.c_int, C.c_int64, c_p)
+_sig("vk_side_tail", C.c_int, C.POINTER(TailJob), C.c_int, c_p)
 _sig("vk_run_ops", C.c_int, C.POINTER(Op), C.c_int, c_p)
 _sig("vk_run_ops_timed", C.c_int, C.POINTER(Op), C.c_int, c_p, C.POINTER(C.c_float))
 _sig("vk_ln_bwd_finalize", C.c_int, C.POINTER(LnBwdArgs), c_p)
@@ -181,14 +193,14 @@ _sig("vk_concap_batch", C.c_int, C.POINTER(ConcapArgs), c_p)
 _sig("vk_side_join", C.c_int, c_p)
 _sig("vk_side_enable", None, C.c_int)
 
-EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_cast_f32_bf16", "vk_gemm_grouped",
+EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_cast_f32_bf16", "vk_gemm_grouped", "vk_gemm_grouped_ex",
            "vk_ln_fwd", "vk_ln_fwd_pair", "vk_ln_bwd_partial_rows", "vk_ln_bwd", "vk_ln_bwd_pair", "vk_ln_bwd_finalize", "vk_gated_attn_fwd", "vk_gated_attn_bwd",
            "vk_embed_sum_fwd", "vk_embed_sum_bwd", "vk_rows32", "vk_loc_linear_fwd", "vk_loc_linear_bwd",
            "vk_add_dropout", "vk_colsum_bf16", "vk_vlbert_prep_fwd", "vk_vlbert_maskgrad", "vk_rowgroup_sum_bf16",
            "vk_relu_bwd_bf16", "vk_copy_async", "vk_select_rows", "vk_gather_rows", "vk_scatter_rows_add", "vk_xent_fwd",
            "vk_xent_bwd", "vk_kl_fwd", "vk_kl_bwd", "vk_loss_finalize", "vk_pool_mul_fwd", "vk_pool_mul_bwd",
            "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_grad_norm_clip_masked", "vk_adamw_step",
-           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_enable", "vk_concap_batch"]
+           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_side_tail", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_enable", "vk_concap_batch"]
 
 
 def check(rc):

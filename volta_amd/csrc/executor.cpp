@@ -146,6 +146,7 @@ static int run_one(const vk_op& o, int i, vk_stream_t s) {
                     case VK_FN_RELU_BWD: rc = vk_relu_bwd_bf16(g->p[0], g->p[1], g->p[2], g->n[0], s); break;
                     case VK_FN_COPY: rc = vk_copy_async(g->p[0], g->p[1], g->n[0], s); break;
                     case VK_FN_SUM_SLABS_BF16: rc = vk_sum_slabs_bf16(g->p[0], (const float*)g->p[1], g->n[0], (int)g->n[1], g->n[2], (const int32_t*)g->p[2], (int)g->n[3], s); break;
+                    case VK_FN_SIDE_TAIL: rc = vk_side_tail((const vk_tail_job*)g->p[0], (int)g->n[0], s); break;
                     case VK_FN_SUM_SLABS: rc = vk_sum_slabs_f32((float*)g->p[0], (const float*)g->p[1], g->n[0], (int)g->n[1], g->n[2], s); break;
                     default: rc = vk::set_error("vk_run_ops: unknown generic fn %d at op %d", g->fn, i);
                 }

@@ -204,8 +204,7 @@ static int launch_cfg(int epi, const KGroup& g, int total, hipStream_t s) {
 #define VK_CASE(E)                                                                                        \
     case E: {                                                                                             \
         auto k = gemm_kernel<AT, BT, E, WM, WN, REGSTAGE, TM>;                                                \
-        static bool once = false;                                                                         \
-        if (!once) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; } \
+        static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); (void)attr; /* once per process, thread-safe */ \
         hipLaunchKernelGGL(k, dim3(total), dim3(G::THREADS), LDS, s, g);                                  \
         break;                                                                                            \
     }
@@ -217,12 +216,22 @@ static int launch_cfg(int epi, const KGroup& g, int total, hipStream_t s) {
     return check_launch("vk_gemm_grouped");
 }
 
-static int g_tile_override = 0;       // tuning hook: 0 = heuristic, 128 / 256 / 258 / 259 force a geometry (see vk_gemm_grouped)
-static int g_stagger = 1;
-static int g_min_tiles256_tn = 50;   // TN (weight gradients, side stream): fewer, longer workgroups leave more CUs to the critical path (19.71 -> 19.54 ms)
-static int g_min_tiles256 = 160;   // fewest 256 x 256 tiles for which that geometry is chosen (256 CUs)
-static int g_debug = 0;            // ablation switches of the 256 x 256 kernel (gemm256.hip)
-static int g_regstage_override = -1;  // -1 = heuristic, 0 / 1 = force LDS-DMA / register staging (128^2 only)
+// Geometry selection constants (measured).  In VK_STUDY builds (libvolta_hip_study.so, tools/ only) they can be
+// overridden through exported setters / the environment; the shipped library has no mutable dispatch state.
+#ifdef VK_STUDY
+#define VK_TUNABLE static int
+#else
+#define VK_TUNABLE static constexpr int
+#endif
+VK_TUNABLE g_stagger = 1;
+VK_TUNABLE g_min_tiles256_tn = 50;   // TN (weight gradients, side stream): fewer, longer workgroups leave more CUs to the critical path (19.71 -> 19.54 ms)
+VK_TUNABLE g_min_tiles256 = 160;     // fewest 256 x 256 tiles for which that geometry is chosen (256 CUs)
+VK_TUNABLE g_debug = 0;              // ablation switches of the 4-phase study kernel (gemm256.hip)
+VK_TUNABLE g_regstage_override = -1; // -1 = heuristic, 0 / 1 = force LDS-DMA / register staging (128^2 only)
+VK_TUNABLE g_persistent = 1;         // 0: never take the persistent kernel
+#ifdef VK_STUDY
+static int g_tile_override = 0;      // geometry forced for plain vk_gemm_grouped calls (0 = heuristic)
+#endif
 
 static int total_tiles(const vk_gemm_problem* probs, int nprob, int epilogue, int bm, int bn) {
     int total = 0;
@@ -237,10 +246,11 @@ static int total_tiles(const vk_gemm_problem* probs, int nprob, int epilogue, in
 
 }  // namespace vk
 
-extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, vk_stream_t stream) {
+static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, int geometry, vk_stream_t stream) {
     using namespace vk;
     if (nprob < 1 || nprob > VK_GEMM_MAX_GROUP) return set_error("vk_gemm_grouped: nprob %d out of range", nprob);
     const bool f32out = epilogue == VK_EPI_F32 || epilogue == VK_EPI_F32_ACC;
+    bool any_dyn = false;
     for (int i = 0; i < nprob; ++i) {
         const vk_gemm_problem& q = probs[i];
         if (q.M < 0 || q.N <= 0 || q.K < 0) return set_error("vk_gemm_grouped: bad shape %d %d %d", q.M, q.N, q.K);
@@ -252,20 +262,27 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
         if (layout != VK_TN && q.bias_grad) return set_error("vk_gemm_grouped: bias_grad is a TN (wgrad) feature");
         if ((epilogue == VK_EPI_MULR || epilogue == VK_EPI_ADDR) && !q.R) return set_error("vk_gemm_grouped: R missing");
         if (epilogue == VK_EPI_GELU && !q.C2) return set_error("vk_gemm_grouped: C2 missing");
+        any_dyn |= q.dyn != nullptr;
     }
-    static const bool env_once = [] {       // tuning overrides from the environment (tools only; unset in production)
+#ifdef VK_STUDY
+    static const bool env_once = [] {       // tuning overrides from the environment (study builds only)
         if (const char* e = getenv("VK_GEMM_MIN_TILES256")) g_min_tiles256 = atoi(e);
         if (const char* e = getenv("VK_GEMM_MIN_TILES256_TN")) g_min_tiles256_tn = atoi(e);
         if (const char* e = getenv("VK_GEMM_TILE")) g_tile_override = atoi(e);
+        if (const char* e = getenv("VK_GEMM_PERSISTENT")) g_persistent = atoi(e);
         return true;
     }();
     (void)env_once;
-    // Geometry (tuning hook values in brackets): 128 x 128 [128], 256 x 256 K-split [258], 256 x 192 K-split [259], 256 x 128 K-split [260, study only: never faster than 128 x 128 on the model shapes],
-    // 256 x 256 4-phase [256].  The heuristic takes 256-row tiles whenever they still
+    if (geometry == 0) geometry = g_tile_override;
+#endif
+    // Geometry codes: 128 x 128 [128], 256 x 256 K-split [258], 256 x 192 K-split [259], 256 x 128 K-split [260: never faster than
+    // 128 x 128 on the model shapes], 4-phase study kernel [256, study builds]; + VK_GEMM_PERSISTENT / VK_GEMM_ONE_TILE_PER_WG force the
+    // tile walk.  The heuristic takes 256-row tiles whenever they still
     // yield >= g_min_tiles256 workgroups, and of the two widths the one with less work on the busiest CU:
     // rounds(tiles / 256 CUs) x tile width.  N = 768 -> 4 column tiles of 192 instead of 3 of 256 (228 instead of
     // 171 workgroups for the ViLBERT row counts: one round of smaller tiles), N = 2304 -> 12 instead of 9.
-    int edge = g_tile_override;
+    const int walk = geometry & (VK_GEMM_PERSISTENT | VK_GEMM_ONE_TILE_PER_WG);
+    int edge = geometry & 0xFFF;
     if (edge == 0) {
         const int t256 = total_tiles(probs, nprob, epilogue, 256, 256), t192 = total_tiles(probs, nprob, epilogue, 256, 192);
         if (t256 < (layout == VK_TN ? g_min_tiles256_tn : g_min_tiles256)) edge = 128;
@@ -288,8 +305,7 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
     g.stagger = (g_stagger & 0xFF) | ((g_debug & 0xFF) << 8);
     // Problems with a device-side row count (heads on labelled rows) keep only their first few row tiles alive; the
     // XCD-chunked order would hand all of them to XCD 0 (LM decoder: 240 live tiles on 32 CUs, 188 us instead of ~40).
-    for (int i = 0; i < nprob; ++i)
-        if (probs[i].dyn) g.stagger |= GROUP_PLAIN_ORDER;
+    if (any_dyn) g.stagger |= GROUP_PLAIN_ORDER;
     int total = 0;
     for (int i = 0; i < nprob; ++i) {
         const vk_gemm_problem& q = probs[i];
@@ -304,7 +320,15 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
     }
     if (total == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (edge == 256 || edge == 258 || edge == 259 || edge == 260) return launch_gemm256(layout, epilogue, g, total, s, edge == 258 ? 4 : edge == 259 ? 3 : edge == 260 ? 2 : 0);
+    if (edge == 256 || edge == 258 || edge == 259 || edge == 260) {
+        // more than one round of tiles: one workgroup per CU walks the list (gemm256p_kernel); device-side row counts keep the
+        // one-tile-per-workgroup launch (dead tiles exit at once there)
+        bool persistent = (edge == 258 || edge == 259) && layout != VK_TN && !any_dyn;
+        if (walk == VK_GEMM_PERSISTENT) persistent = persistent && true;
+        else if (walk == VK_GEMM_ONE_TILE_PER_WG) persistent = false;
+        else persistent = persistent && g_persistent && total > NUM_CU;
+        return launch_gemm256(layout, epilogue, g, total, s, edge == 258 ? 4 : edge == 259 ? 3 : edge == 260 ? 2 : 0, persistent);
+    }
     {
         const bool reg = g_regstage_override >= 0 ? g_regstage_override != 0 : layout != VK_NT;
         if (layout == VK_NT) return reg ? launch_cfg<false, false, 2, 2, true>(epilogue, g, total, s) : launch_cfg<false, false, 2, 2, false>(epilogue, g, total, s);
@@ -314,7 +338,16 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
     return set_error("vk_gemm_grouped: unknown layout %d", layout);
 }
 
-/* tuning hooks for tools/bench_gemm.py (0 / -1 restore the heuristics) */
+extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, vk_stream_t stream) {
+    return gemm_dispatch(layout, epilogue, probs, nprob, 0, stream);
+}
+
+extern "C" int vk_gemm_grouped_ex(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, int geometry, vk_stream_t stream) {
+    return gemm_dispatch(layout, epilogue, probs, nprob, geometry, stream);
+}
+
+#ifdef VK_STUDY
+/* measurement hooks for tools/bench_gemm.py (study builds only) */
 extern "C" int vk_gemm_repeat(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, int iters, vk_stream_t stream) {
     for (int i = 0; i < iters; ++i) {       // back-to-back launches from native code: no interpreter time between kernels
         const int rc = vk_gemm_grouped(layout, epilogue, probs, nprob, stream);
@@ -327,3 +360,5 @@ extern "C" void vk_gemm_set_regstage(int v) { vk::g_regstage_override = v; }
 extern "C" void vk_gemm_set_stagger(int v) { vk::g_stagger = v; }
 extern "C" void vk_gemm_set_debug(int v) { vk::g_debug = v; }
 extern "C" void vk_gemm_set_min_tiles256(int v) { vk::g_min_tiles256 = v; }
+extern "C" void vk_gemm_set_persistent(int v) { vk::g_persistent = v; }
+#endif

@@ -67,6 +67,7 @@ __device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rs, uint32_t s
         __builtin_amdgcn_sched_barrier(0);                     \
     } while (0)
 
+#ifdef VK_STUDY      // the 4-phase kernel and its ablation switches: measurement code, not shipped in libvolta_hip.so
 template <int V> using ic = std::integral_constant<int, V>;
 
 template <bool AT, bool BT, int EPI>
@@ -223,6 +224,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const KGroup g) {
 }
 
 
+#endif  // VK_STUDY
+
 // ---------------------------------------------------------------------------------------------------------
 // Variant B: one phase per 32-deep K-step.  Every phase reads the whole wave tile's fragments (8 A + 4 B,
 // 12 ds_read_b128), issues the DMA of one K-step (A and B strips of 256 x 32, 16 KiB each, 4 instructions per
@@ -359,14 +362,132 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
     gemm_epilogue<AT, EPI, 8, TJ>(P, acc, accb, do_bias_grad, m0 + wr * 128, n0 + wc * WN, M, lane, lds0 + (uint32_t)wave * 16384u);
 }
 
-template <bool AT, bool BT, int KSPLIT>      // 0: 4-phase 256 x 256, 4 / 3 / 2: K-split kernel with 256 / 192 / 128 columns
-static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s) {
+// ---------------------------------------------------------------------------------------------------------
+// Persistent form of the K-split kernel for launches of more than one round of tiles (NT / NN; 684 tiles for the dual-stream
+// Q|K|V, FFN-up and FFN-down-dgrad GEMMs of ViLBERT): one workgroup per CU walks tiles v = blockIdx.x, + gridDim.x, ...
+// Between two tiles the first three K-steps of the NEXT tile are requested (ring slots 0-2) BEFORE the epilogue of the current one
+// runs out of slots 3-4 (8 KiB per wave), so the epilogue's conversion / LDS transposition / store issue hides the operand latency
+// of the next tile, the output stores drain into L2 under the next tile's K loop instead of holding the CU until the workgroup
+// retires, and launch ramp + end-of-kernel write-back are paid once per launch instead of once per round.
+// vmcnt counts loads and stores together in issue order: the next tile's prologue loads are OLDER than the epilogue's stores, so the
+// loop's first `vmcnt(8)` (all but the 8 youngest operations done) covers them -- conservatively, it also waits for most stores.
+template <bool AT, bool BT, int EPI, int TJ>
+__global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int total) {
+    static_assert(!(AT && BT), "the persistent kernel serves the NT / NN layouts (no bias-gradient accumulators)");
+    constexpr int RING = 5;
+    constexpr int BN = 64 * TJ, WN = 16 * TJ;
+    constexpr uint32_t EPI_BASE = 6u * HT, EPI_REGION = 8192u;       // ring slots 3 and 4
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(VK_LDS char*)smem;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+
+    int pi, m0, n0, np;
+    __amdgpu_buffer_rsrc_t rsA, rsB;
+    uint32_t offA[2], offB[2], kA, kB;
+    auto setup = [&](int v) {
+        const int bid = xcd_remap(v, total);
+        pi = 0;
+#pragma nounroll
+        for (int i = 1; i < g.nprob; ++i)              // scalar loop: an unrolled search keeps 32 tile_start words live across the tile loop
+            if (bid >= g.p[i].tile_start) pi = i;
+        const KProb& P = g.p[pi];
+        const int t = bid - P.tile_start;
+        const int tm = t / P.tiles_n, tn = t - tm * P.tiles_n;
+        m0 = tm * 256; n0 = tn * BN;
+        const int M = P.M, K = P.K;
+        const int a_rows = AT ? K : M, a_cols = AT ? P.lda : K;
+        const int b_rows = BT ? K : P.N, b_cols = BT ? P.ldb : K;
+        rsA = make_rsrc(P.A, a_rows > 0 ? (uint32_t)(((uint32_t)(a_rows - 1) * P.lda + a_cols) * 2u) : 0u);
+        rsB = make_rsrc(P.B, b_rows > 0 ? (uint32_t)(((uint32_t)(b_rows - 1) * P.ldb + b_cols) * 2u) : 0u);
+        strip_offsets<AT>(offA, P.lda, m0, 256, tid);
+        strip_offsets<BT>(offB, P.ldb, n0, BN, tid);
+        kA = AT ? 64u * (uint32_t)P.lda : 64u; kB = BT ? 64u * (uint32_t)P.ldb : 64u;
+        np = (K + 31) / 32;
+    };
+    auto stage = [&](int p, int slot) {
+        const bool live = p < np;
+        const uint32_t sa = lds0 + (uint32_t)slot * 2u * HT;
+        stage_half(rsA, sa, offA, live ? (uint32_t)p * kA : OOB, wave);
+        stage_half(rsB, sa + HT, offB, live ? (uint32_t)p * kB : OOB, wave);
+    };
+
+    int v = blockIdx.x;
+    setup(v);
+    stage(0, 0); stage(1, 1); stage(2, 2);
+    for (;;) {
+        f32x4 acc[8][TJ];
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        VK_WAIT_DMA();
+        VK_SYNC();
+        if (wr == 1) VK_SYNC();        // the upper half of the workgroup runs half a phase behind
+        int rd = 0, wrs = 3;
+        for (int p = 0; p < np; ++p) {
+            const uint32_t sa = lds0 + (uint32_t)rd * 2u * HT, sb = sa + HT;
+            bf16x8 a[8], b[TJ];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) b[j] = BT ? frag_cols<512>(sb, wc * WN + j * 16, 0, lane) : frag_strip(sb, wc * WN + j * 16, lane);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) a[i] = AT ? frag_cols<512>(sa, wr * 128 + i * 16, 0, lane) : frag_strip(sa, wr * 128 + i * 16, lane);
+            stage(p + 3, wrs);
+            VK_WAIT_DMA();
+            VK_SYNC();
+            VK_WAIT_LDS();
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+#pragma unroll
+                for (int j = 0; j < TJ; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            VK_SYNC();
+            rd = rd == RING - 1 ? 0 : rd + 1;
+            wrs = wrs == RING - 1 ? 0 : wrs + 1;
+        }
+        if (wr == 0) VK_SYNC();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // retire the zero-fill stages issued past the end of K
+        VK_SYNC();                                            // ... of every wave: the whole ring is free
+
+        const int cpi = pi, cm0 = m0, cn0 = n0;
+        const int nv = v + (int)gridDim.x;
+        const bool more = nv < total;
+        if (more) {                                           // next tile's operands first, then this tile's output
+            setup(nv);
+            stage(0, 0); stage(1, 1); stage(2, 2);
+        }
+        f32x4 accb[8];
+        gemm_epilogue<AT, EPI, 8, TJ, (int)EPI_REGION>(g.p[cpi], acc, accb, false, cm0 + wr * 128, cn0 + wc * WN, g.p[cpi].M, lane,
+                                                       lds0 + EPI_BASE + (uint32_t)wave * EPI_REGION);
+        if (!more) break;
+        v = nv;
+    }
+}
+
+template <bool AT, bool BT, int KSPLIT>      // 4 / 3 / 2: K-split kernel with 256 / 192 / 128 columns; 0: 4-phase 256 x 256 (study builds)
+static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s, bool persistent) {
     constexpr int LDS = (KSPLIT ? 10 : 8) * HT;
+#ifdef VK_STUDY
+#define VK_KERNEL_OF(E) (KSPLIT == 2 ? gemm256k_kernel<AT, BT, E, 2> : KSPLIT == 3 ? gemm256k_kernel<AT, BT, E, 3> : KSPLIT == 4 ? gemm256k_kernel<AT, BT, E, 4> : gemm256_kernel<AT, BT, E>)
+#else
+#define VK_KERNEL_OF(E) (KSPLIT == 2 ? gemm256k_kernel<AT, BT, E, 2> : KSPLIT == 3 ? gemm256k_kernel<AT, BT, E, 3> : gemm256k_kernel<AT, BT, E, 4>)
+#endif
 #define VK_CASE(E)                                                                                        \
     case E: {                                                                                             \
-        auto k = KSPLIT == 2 ? gemm256k_kernel<AT, BT, E, 2> : KSPLIT == 3 ? gemm256k_kernel<AT, BT, E, 3> : KSPLIT == 4 ? gemm256k_kernel<AT, BT, E, 4> : gemm256_kernel<AT, BT, E>; \
-        static bool once = false;                                                                         \
-        if (!once) { (void)hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); once = true; } \
+        if constexpr (!(AT && BT) && (KSPLIT == 3 || KSPLIT == 4)) {                                      \
+            if (persistent) {                                                                             \
+                auto kp = gemm256p_kernel<AT, BT, E, KSPLIT>;                                             \
+                static const hipError_t attr_p = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); (void)attr_p; \
+                hipLaunchKernelGGL(kp, dim3(total < NUM_CU ? total : NUM_CU), dim3(512), LDS, s, g, total); \
+                break;                                                                                    \
+            }                                                                                             \
+        }                                                                                                 \
+        auto k = VK_KERNEL_OF(E);                                                                         \
+        static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); (void)attr; /* once per process, thread-safe */ \
         hipLaunchKernelGGL(k, dim3(total), dim3(512), LDS, s, g);                                         \
         break;                                                                                            \
     }
@@ -375,29 +496,27 @@ static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s) {
         default: return set_error("vk_gemm_grouped: unknown epilogue %d", epi);
     }
 #undef VK_CASE
+#undef VK_KERNEL_OF
     return check_launch("vk_gemm_grouped");
 }
 
-int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant) {
-    if (variant == 2) {
-        if (layout == VK_NT) return launch_layout<false, false, 2>(epilogue, g, total, s);
-        if (layout == VK_NN) return launch_layout<false, true, 2>(epilogue, g, total, s);
-        if (layout == VK_TN) return launch_layout<true, true, 2>(epilogue, g, total, s);
-    }
-    if (variant == 3) {
-        if (layout == VK_NT) return launch_layout<false, false, 3>(epilogue, g, total, s);
-        if (layout == VK_NN) return launch_layout<false, true, 3>(epilogue, g, total, s);
-        if (layout == VK_TN) return launch_layout<true, true, 3>(epilogue, g, total, s);
-    }
-    if (variant == 4) {
-        if (layout == VK_NT) return launch_layout<false, false, 4>(epilogue, g, total, s);
-        if (layout == VK_NN) return launch_layout<false, true, 4>(epilogue, g, total, s);
-        if (layout == VK_TN) return launch_layout<true, true, 4>(epilogue, g, total, s);
-    }
-    if (layout == VK_NT) return launch_layout<false, false, 0>(epilogue, g, total, s);
-    if (layout == VK_NN) return launch_layout<false, true, 0>(epilogue, g, total, s);
-    if (layout == VK_TN) return launch_layout<true, true, 0>(epilogue, g, total, s);
+template <int KSPLIT>
+static int launch_variant(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, bool persistent) {
+    if (layout == VK_NT) return launch_layout<false, false, KSPLIT>(epilogue, g, total, s, persistent);
+    if (layout == VK_NN) return launch_layout<false, true, KSPLIT>(epilogue, g, total, s, persistent);
+    if (layout == VK_TN) return launch_layout<true, true, KSPLIT>(epilogue, g, total, s, false);
     return set_error("vk_gemm_grouped: unknown layout %d", layout);
+}
+
+int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant, bool persistent) {
+    if (variant == 2) return launch_variant<2>(layout, epilogue, g, total, s, false);
+    if (variant == 3) return launch_variant<3>(layout, epilogue, g, total, s, persistent);
+    if (variant == 4) return launch_variant<4>(layout, epilogue, g, total, s, persistent);
+#ifdef VK_STUDY
+    return launch_variant<0>(layout, epilogue, g, total, s, false);
+#else
+    return set_error("vk_gemm_grouped: geometry variant %d is not part of this build", variant);
+#endif
 }
 
 }  // namespace vk

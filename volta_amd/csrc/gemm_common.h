@@ -62,7 +62,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // Every global READ of the epilogue (bias, residual / multiplier R, accumulate-into C) is an unconditional
 // bounds-checked buffer load -- absent operands and out-of-range rows / columns read as 0 -- so the compiler can
 // issue them all up front instead of one dependent L2 round trip per element; only the stores are predicated.
-template <bool AT, int EPI, int TI, int TJ>
+template <bool AT, int EPI, int TI, int TJ, int REGION = 16384>       // REGION: bytes of the wave-private LDS staging region
 __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][TJ], f32x4 (&accb)[TI], bool do_bias_grad,
                                               int m_base, int n_base, int M, int lane, uint32_t lds_region = 0) {
     const int gq = lane >> 4, lr = lane & 15;
@@ -86,13 +86,13 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
         constexpr bool POW2 = (TJ & (TJ - 1)) == 0;            // XOR swizzle needs 2^k chunks per row; otherwise rows are padded by 16 bytes
         constexpr int PITCH = POW2 ? ROWB : ROWB + 16;
         constexpr int NIMG = (EPI == VK_EPI_GELU) ? 2 : 1;
-        constexpr int RPH0 = 16384 / (PITCH * NIMG);           // rows per pass through the 16 KiB region
+        constexpr int RPH0 = REGION / (PITCH * NIMG);          // rows per pass through the staging region
         constexpr int TIH = RPH0 >= TI * 16 ? TI : (RPH0 >= TI * 8 ? TI / 2 : TI / 4);    // row tiles per pass (divides TI)
         constexpr int RPH = TIH * 16;
         constexpr int CPR = ROWB / 16;                         // 16-byte chunks per row
         constexpr int RPI = 64 / CPR;                          // rows per store instruction
         constexpr int SWZ = POW2 ? (CPR < 8 ? CPR - 1 : 7) : 0; // XOR mask of the chunk swizzle (stays inside the row: 4 chunks for 256 x 128 bf16 tiles)
-        static_assert(TIH >= 1 && RPH * PITCH * NIMG <= 16384, "epilogue staging does not fit its 16 KiB region");
+        static_assert(TIH >= 1 && RPH * PITCH * NIMG <= REGION, "epilogue staging does not fit its region");
         const bool via_lds = lds_region != 0 && ((ldc * ES) & 15) == 0 && (((uintptr_t)Cp | (uintptr_t)C2p) & 15) == 0;
         const uint32_t img2 = lds_region + RPH * PITCH;
         f32x4 b4[TJ];
@@ -105,17 +105,20 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
         }
         // the residual / multiplier operand of the whole wave tile is requested up front: one L2 round trip instead of
         // one per row of tiles (2 VGPRs per tile; the K loop's fragment registers are free by now)
-        u32x2 rall[USE_R ? TI : 1][TJ];
-        if (USE_R) {
-#pragma unroll
-            for (int i = 0; i < TI; ++i) {
-                const char* rrow = Rp + ((size_t)(m_base + i * 16 + lr) * ldr + (size_t)(n_base + gq * 4)) * 2;
-#pragma unroll
-                for (int j = 0; j < TJ; ++j) rall[i][j] = *(const u32x2*)(rrow + j * 32);
-            }
-        }
+        // (the persistent kernel keeps the next tile's staging offsets live beside the accumulators: its 256-wide tiles request R in
+        // two batches of TI / 2 rows of tiles instead of all at once, 32 instead of 64 VGPRs)
+        constexpr int RB = (REGION < 16384 && TJ >= 4) ? TI / 2 : TI;
+        u32x2 rall[USE_R ? RB : 1][TJ];
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
+            if (USE_R && (i % RB) == 0) {
+#pragma unroll
+                for (int ii = 0; ii < RB; ++ii) {
+                    const char* rrow = Rp + ((size_t)(m_base + (i + ii) * 16 + lr) * ldr + (size_t)(n_base + gq * 4)) * 2;
+#pragma unroll
+                    for (int j = 0; j < TJ; ++j) rall[ii][j] = *(const u32x2*)(rrow + j * 32);
+                }
+            }
             __builtin_amdgcn_sched_barrier(0);
             const int m = m_base + i * 16 + lr;
             const int lrow = (i % TIH) * 16 + lr;              // row inside the LDS image
@@ -124,7 +127,7 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
             f32x4 cv[TJ];
             if (USE_R) {
 #pragma unroll
-                for (int j = 0; j < TJ; ++j) rv[j] = rall[i][j];
+                for (int j = 0; j < TJ; ++j) rv[j] = rall[i % RB][j];
             }
             if (EPI == VK_EPI_F32_ACC) {
 #pragma unroll
@@ -280,7 +283,9 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
     }
 }
 
-// 256 x 256 tile, 8 waves, 8-phase LDS-DMA pipeline (gemm256.hip)
-int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant);   // 0: 4-phase, 4 / 3: K-split with 256 / 192 columns
+// 256-row tiles, 8 waves, LDS-DMA ring (gemm256.hip).  variant 4 / 3 / 2: K-split kernel with 256 / 192 / 128 columns; 0: the 4-phase
+// study kernel (VK_STUDY builds only).  persistent: one workgroup per CU walks the tile list (NT / NN, no device-side row counts).
+constexpr int NUM_CU = 256;       // MI355X
+int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant, bool persistent);
 
 }  // namespace vk

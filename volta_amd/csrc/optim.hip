@@ -109,9 +109,83 @@ __global__ __launch_bounds__(256) void sum_slabs_bf16_kernel(uint16_t* dst, cons
     }
 }
 
+struct TailJobs { vk_tail_job j[VK_TAIL_MAX_JOBS]; int32_t njobs; };
+
+// One launch for every small reduction that ends a sub-layer's weight-gradient block (96 slab sums + 64 LayerNorm column
+// reductions per ViLBERT step used to be 160 launches of 5-13 us on the side stream).  Workgroup -> job by block_start.
+__global__ __launch_bounds__(256) void side_tail_kernel(const TailJobs t) {
+    __shared__ float red[16][17];
+    int ji = 0;
+#pragma unroll
+    for (int i = 1; i < VK_TAIL_MAX_JOBS; ++i)
+        if (i < t.njobs && (int)blockIdx.x >= t.j[i].block_start) ji = i;
+    const vk_tail_job& J = t.j[ji];
+    const int blk = (int)blockIdx.x - J.block_start;
+    if (J.kind == 0) {
+        const size_t n4 = (size_t)J.n >> 2;
+        const size_t i = (size_t)blk * 256 + threadIdx.x;
+        if (i < n4) {
+            f32x4 a = *(const f32x4*)(J.src + i * 4);
+            for (int s = 1; s < J.count; ++s) {
+                const f32x4 b = *(const f32x4*)(J.src + (size_t)s * J.stride + i * 4);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a[r] += b[r];
+            }
+            *(f32x4*)(J.dst + i * 4) = a;
+        }
+        if (blk == 0 && threadIdx.x < (J.n & 3)) {
+            const size_t k = n4 * 4 + threadIdx.x;
+            float a = 0.f;
+            for (int s = 0; s < J.count; ++s) a += J.src[(size_t)s * J.stride + k];
+            J.dst[k] = a;
+        }
+    } else {
+        // 16 columns x 16 row groups per workgroup over the [count][2 H] partial records
+        const int H = (int)J.n, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+        const int i = blk * 16 + tx;
+        float s = 0.f;
+        if (i < 2 * H)
+            for (int b = ty; b < J.count; b += 16) s += J.src[(size_t)b * 2 * H + i];
+        red[ty][tx] = s;
+        __syncthreads();
+        if (ty == 0 && i < 2 * H) {
+#pragma unroll
+            for (int k = 1; k < 16; ++k) s += red[k][tx];
+            float* o = i < H ? J.dst + i : J.dst2 + (i - H);
+            *o = J.accumulate ? *o + s : s;
+        }
+    }
+}
+
 }  // namespace vk
 
 using namespace vk;
+
+extern "C" int vk_side_tail(const vk_tail_job* jobs, int njobs, vk_stream_t s) {
+    if (njobs <= 0) return 0;
+    if (njobs > VK_TAIL_MAX_JOBS) return set_error("vk_side_tail: %d jobs (max %d)", njobs, VK_TAIL_MAX_JOBS);
+    TailJobs t;
+    t.njobs = njobs;
+    int total = 0;
+    for (int i = 0; i < njobs; ++i) {
+        t.j[i] = jobs[i];
+        vk_tail_job& J = t.j[i];
+        int nb;
+        if (J.kind == 0) {
+            if ((J.stride & 3) || ((uintptr_t)J.dst & 15) || ((uintptr_t)J.src & 15)) return set_error("vk_side_tail: slab job %d needs 16-byte alignment", i);
+            nb = (int)((J.n / 4 + 255) / 256);
+            if (nb < 1) nb = 1;
+        } else if (J.kind == 1) {
+            nb = (int)((2 * J.n + 15) / 16);
+        } else return set_error("vk_side_tail: unknown job kind %d", J.kind);
+        if (J.n <= 0 || J.count <= 0) nb = 0;
+        J.block_start = total;
+        total += nb;
+    }
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(side_tail_kernel, dim3((unsigned)total), dim3(256), 0, (hipStream_t)s, t);
+    return check_launch("vk_side_tail");
+}
 
 extern "C" int vk_sum_slabs_bf16(void* dst, const float* src, int64_t slab_stride, int nslabs, int64_t n, const int32_t* dyn_rows, int row_len, vk_stream_t s) {
     if (n <= 0 || nslabs <= 0) return 0;

@@ -849,11 +849,15 @@ class StepEngine:
         assert len(probs) <= 32, "too many wgrad problems in one group"
         b.append((L.OP_SIDE_BEGIN, 0, 0, 0, None, None, None))
         self.gemm(b, L.TN, L.EPI_F32, probs)
-        for dst, src, stride, ns, n in reduces:
-            b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SUM_SLABS, p=(dst, src), n=(stride, ns, n)), None, None))
+        # every slab sum and every deferred LayerNorm dgamma / dbeta reduction of the sub-layer in ONE launch (vk_side_tail)
+        jobs = [L.TailJob(_addr(dst), None, _addr(src), stride, n, 0, ns, 0, 0) for dst, src, stride, ns, n in reduces]
         for a in getattr(self, "_deferred_ln", []):          # LayerNorm parameter gradients of this sub-layer
-            b.append((L.OP_LN_FINALIZE, 0, 0, 0, a, None, None))
+            jobs.append(L.TailJob(a.dgamma, a.dbeta, a.partial, 0, a.H, 1, L.lib.vk_ln_bwd_partial_rows(a.M), a.accumulate & 1, 0))
         self._deferred_ln = []
+        for i in range(0, len(jobs), L.TAIL_MAX_JOBS):
+            chunk = jobs[i:i + L.TAIL_MAX_JOBS]
+            arr = self.k((L.TailJob * len(chunk))(*chunk))
+            b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SIDE_TAIL, p=(arr,), n=(len(chunk),)), None, None))
         b.append((L.OP_SIDE_END, self.sub_k % 8, 0, 0, None, None, None))
         self._slab_cursor = 0
 

@@ -46,9 +46,13 @@ def gemm_problem(A, B, Cout, layout, M, N, K, bias=None, R=None, C2=None, bias_g
                          M, N, K, lda, ldb, ldc, ldr or 0, n_store)
 
 
-def gemm_grouped(layout, epilogue, problems):
+default_geometry = 0      # what gemm_grouped() passes when the caller names none (the parity tests sweep it; 0 = the library's heuristic)
+
+
+def gemm_grouped(layout, epilogue, problems, geometry=None):
+    """geometry: tile code of vk_gemm_grouped_ex (128 / 258 / 259 / 260, | L.GEMM_PERSISTENT / L.GEMM_ONE_TILE_PER_WG), 0 = heuristic."""
     arr = (L.GemmProblem * len(problems))(*problems)
-    check(L.lib.vk_gemm_grouped(layout, epilogue, arr, len(problems), stream_ptr()))
+    check(L.lib.vk_gemm_grouped_ex(layout, epilogue, arr, len(problems), default_geometry if geometry is None else geometry, stream_ptr()))
 
 
 def cast_f32_bf16(src, dst):
