@@ -24,6 +24,7 @@ sys.path.insert(0, ROOT)
 GFLOP_PER_PAIR = {("ctrl_vilbert_base", 20, 36): 37.876, ("ctrl_vilbert_base", 38, 36): 54.420, ("ctrl_lxmert", 20, 36): 35.415,
                   ("ctrl_uniter_base", 20, 36): 32.937, ("ctrl_visualbert_base", 20, 36): 32.937, ("ctrl_vl-bert_base", 20, 100): 69.184}
 PEAK_BF16_TFLOPS = 2500.0        # MI355X dense bf16 MFMA peak (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_FP8_TFLOPS = 5000.0         # dense fp8 MFMA peak: the yardstick BASELINE.json configs[4] names for --dtype fp8
 
 
 def parse():
@@ -48,11 +49,11 @@ def gemm_flops(eng, plan):
     from volta_amd import _lib as L
     out = {}
     for i, (kind, layout, epi, nprob, arr, _, _) in enumerate(plan.ops):
-        if kind != L.OP_GEMM:
+        if kind not in (L.OP_GEMM, L.OP_GEMM_FP8):
             continue
         fl = 0.0
         for j in range(nprob):
-            q = arr[j]
+            q = arr[j].p if kind == L.OP_GEMM_FP8 else arr[j]
             M, K = q.M, q.K
             if q.dyn:
                 n = int(_dev_int(q.dyn, eng).item())
@@ -246,6 +247,8 @@ def main():
     model = BertForVLPreTraining(cfg).cuda()
     model.train()
     model.materialize()
+    model.set_projection_dtype(a.dtype)
+    peak = PEAK_FP8_TFLOPS if a.dtype == "fp8" else PEAK_BF16_TFLOPS
     net = DistributedDataParallel(model) if world > 1 else model
     no_decay = ("bias", "LayerNorm.bias", "LayerNorm.weight")
     groups = [{"params": [p], "lr": 1e-4, "weight_decay": 0.0 if any(nd in n for nd in no_decay) else 0.01}
@@ -292,8 +295,11 @@ def main():
         print("[bench] timed region done: %.3f ms/step, %.1f pairs/s" % (ms, pairs_s), file=sys.stderr, flush=True)
         if gflop is not None:
             ach = pairs_s / world * gflop / 1e3            # per-GPU TFLOP/s
-            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS,
+            out["roofline"] = {"bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
                                "traffic": None, "scope": "whole step: pairs/s x %.3f GFLOP/pair (reference-graph matmul FLOPs, BASELINE.md)" % gflop}
+            if a.dtype == "fp8":
+                out["roofline"]["peak_note"] = ("dense fp8 MFMA peak; only the forward Q|K|V / FFN projections run on the e4m3 MFMA, attention output, "
+                                                "heads and the whole backward stay bf16 (peak 2500)")
         if not a.no_kernel_timing and world == 1:      # extra profiled steps would desynchronise the ranks' collectives
             eng = model._last[0]
             eng.fwd.enable_timing(True)
@@ -311,16 +317,17 @@ def main():
             kinds = {}
             for plan, tag in ((eng.fwd, "f"), (eng.bwd, "b")):
                 for i, op in enumerate(plan.ops):
-                    name = {L.OP_GEMM: "gemm", L.OP_LN_FWD: "ln_fwd", L.OP_LN_BWD: "ln_bwd", L.OP_ATTN_FWD: "attn_fwd", L.OP_ATTN_BWD: "attn_bwd"}.get(op[0], "other")
+                    name = {L.OP_GEMM: "gemm", L.OP_GEMM_FP8: "gemm_fp8", L.OP_LN_FWD: "ln_fwd", L.OP_LN_BWD: "ln_bwd", L.OP_ATTN_FWD: "attn_fwd", L.OP_ATTN_BWD: "attn_bwd"}.get(op[0], "other")
                     kinds[name] = kinds.get(name, 0.0) + tms["%s%d" % (tag, i)]
             if a.dump_ops:
                 with open(a.dump_ops, "w") as fh:
                     for plan, tag in ((eng.fwd, "f"), (eng.bwd, "b")):
                         for i, op in enumerate(plan.ops):
                             key = "%s%d" % (tag, i)
-                            if op[0] == L.OP_GEMM:
+                            if op[0] in (L.OP_GEMM, L.OP_GEMM_FP8):
                                 arr, nprob = op[4], op[3]
-                                shapes = ";".join("%dx%dx%d" % (arr[j].M, arr[j].N, arr[j].K) for j in range(min(nprob, 4)))
+                                pr = [(arr[j].p if op[0] == L.OP_GEMM_FP8 else arr[j]) for j in range(min(nprob, 4))]
+                                shapes = ("fp8 " if op[0] == L.OP_GEMM_FP8 else "") + ";".join("%dx%dx%d" % (q.M, q.N, q.K) for q in pr)
                                 fh.write("%s gemm layout=%d epi=%d nprob=%d [%s] %.1f us %.0f TF/s\n" % (key, op[1], op[2], nprob, shapes, tms[key] * 1e3, fl[key] / (tms[key] * 1e-3) / 1e12))
                             else:
                                 fh.write("%s kind=%d %.1f us\n" % (key, op[0], tms[key] * 1e3))
@@ -333,7 +340,8 @@ def main():
             whole = out["roofline"]
             out["roofline"] = {
                 "bound": "mfma", "achieved": ach, "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_BF16_TFLOPS, "traffic": None,
-                "kernel": "vk::gemm256k_kernel / vk::gemm_kernel (bf16 MFMA 16x16x32 GEMM family, all layouts and epilogues)",
+                "kernel": "vk::gemm256k_kernel / gemm256p_kernel / gemm_kernel (bf16 MFMA 16x16x32 GEMM family, all layouts and epilogues)"
+                          + (" + vk::gemm_fp8_kernel (e4m3 MFMA 16x16x128, forward projections); priced against the bf16 peak" if a.dtype == "fp8" else ""),
                 "launches_per_step": len(fl), "algorithmic_gflop_per_launch": gemm_fl / 1e9 / len(fl), "avg_launch_us": gemm_ms * 1e3 / len(fl),
                 "ms_per_step": gemm_ms, "timing": "HIP events on the launch stream around every launch, %d profiled steps, serial schedule" % nprof,
                 "sustained_mfma_note": "a register-only MFMA loop sustains ~1.75-2.0 PFLOP/s on this part (tools/bench_gemm.py peak); `peak` is the datasheet 2.5",

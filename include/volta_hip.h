@@ -84,6 +84,24 @@ int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* probs, int 
 #define VK_GEMM_ONE_TILE_PER_WG 0x2000
 int vk_gemm_grouped_ex(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, int geometry, vk_stream_t s);
 
+/* fp8 (OCP e4m3) forward projections on v_mfma_scale_f32_16x16x128_f8f6f4 (BASELINE.json configs[4]; the reference is fp32, the
+ * sites are the nn.Linear forwards of volta/encoders.py:242-255, 495-499, 552-565).  Layout NT only: C[M,N] = (A8[M,K] . B8[N,K]^T)
+ * * scale_a[m] * scale_b[n] (+ bias, epilogue): A8 / B8 are e4m3 bytes, lda / ldb in BYTES (multiples of 16), K padded to a multiple
+ * of 128 by the leading dimensions; scale vectors are the per-row de-quantisation factors written by vk_quant_rows_fp8 (NULL = 1).
+ * Epilogues BF16, GELU, F32, RELU; geometry 0 (heuristic) / 128 / 256.  Gradients stay on the bf16 kernels. */
+#define VK_GEMM_FP8_MAX_GROUP 4
+typedef struct vk_gemm_fp8_problem {
+    vk_gemm_problem p;        /* R, bias_grad unused */
+    const float* scale_a;     /* [M] or NULL */
+    const float* scale_b;     /* [N] or NULL */
+} vk_gemm_fp8_problem;
+int vk_gemm_fp8_grouped(int epilogue, const vk_gemm_fp8_problem* probs, int nprob, int geometry, vk_stream_t s);
+/* Row-wise e4m3 quantisation: scale[m] = max|x[m,:]| / 448 (1 for a zero row), dst[m,k] = rne(x[m,k] / scale[m]); src bf16 (or fp32),
+ * ld / ldq in elements / bytes, K a multiple of 8 and <= 4096; dyn (device int32 or NULL) limits the rows. */
+int vk_quant_rows_fp8(const void* src, int src_is_f32, int64_t ld, void* dst, int64_t ldq, float* scale, int M, int K, const int32_t* dyn, vk_stream_t s);
+/* dst[i] = e4m3(saturate(src[i] * mul)), src bf16: static-scale quantisation of a whole tensor (the GELU output). */
+int vk_cast_bf16_fp8(const void* src, void* dst, int64_t n, float mul, vk_stream_t s);
+
 /* ------------------------------------------------------------------------------------------------
  * Fused (dropout +) residual + LayerNorm.  Replaces apex FusedLayerNormAffineFunction
  * (apex/csrc/layer_norm_cuda.cpp:121-240: forward_affine / backward_affine) and the python fallback
@@ -362,13 +380,16 @@ enum {
        stream; SIDE_END records event i0 (0..15) there, WAIT_SIDE makes the caller's stream wait for event i0 (no-op
        if never recorded), JOIN makes it wait for everything issued on the side stream. */
     VK_OP_SIDE_BEGIN, VK_OP_SIDE_END, VK_OP_WAIT_SIDE, VK_OP_JOIN,
-    VK_OP_LN_FINALIZE    /* a = vk_ln_bwd_args of the deferred vk_ln_bwd */
+    VK_OP_LN_FINALIZE,   /* a = vk_ln_bwd_args of the deferred vk_ln_bwd */
+    VK_OP_GEMM_FP8       /* a = vk_gemm_fp8_problem[i2], i1 = epilogue, i0 = geometry */
 };
 enum {
     VK_FN_CAST = 1, VK_FN_MEMSET, VK_FN_LOC_FWD, VK_FN_LOC_BWD, VK_FN_ADD_DROPOUT, VK_FN_COLSUM, VK_FN_SELECT,
     VK_FN_GATHER, VK_FN_SCATTER_ADD, VK_FN_LOSS_FINAL, VK_FN_POOL_FWD, VK_FN_POOL_BWD, VK_FN_MASK_PREP, VK_FN_MUL,
     VK_FN_VLBERT_PREP, VK_FN_VLBERT_MASKGRAD, VK_FN_ROWGROUP_SUM, VK_FN_RELU_BWD, VK_FN_COPY, VK_FN_SUM_SLABS, VK_FN_SUM_SLABS_BF16,
-    VK_FN_SIDE_TAIL      /* p[0] = vk_tail_job[n[0]] */
+    VK_FN_SIDE_TAIL,     /* p[0] = vk_tail_job[n[0]] */
+    VK_FN_QUANT_ROWS,    /* vk_quant_rows_fp8(p[0], n[4], n[2], p[1], n[3], p[2], n[0], n[1], p[3]) */
+    VK_FN_CAST_FP8       /* vk_cast_bf16_fp8(p[0], p[1], n[0], f[0]) */
 };
 typedef struct vk_generic_args {   /* positional arguments of the small entry points, see executor.cpp */
     int32_t fn;

@@ -112,6 +112,7 @@ static int run_one(const vk_op& o, int i, vk_stream_t s) {
         int rc = 0;
         switch (o.kind) {
             case VK_OP_GEMM: rc = vk_gemm_grouped(o.i0, o.i1, (const vk_gemm_problem*)o.a, o.i2, s); break;
+            case VK_OP_GEMM_FP8: rc = vk_gemm_fp8_grouped(o.i1, (const vk_gemm_fp8_problem*)o.a, o.i2, o.i0, s); break;
             case VK_OP_LN_FWD: rc = vk_ln_fwd_pair((const vk_ln_args*)o.a, (const vk_ln_args*)o.b, s); break;
             case VK_OP_LN_BWD: rc = vk_ln_bwd_pair((const vk_ln_bwd_args*)o.a, (const vk_ln_bwd_args*)o.b, s); break;
             case VK_OP_LN_FINALIZE: rc = vk_ln_bwd_finalize((const vk_ln_bwd_args*)o.a, s); break;
@@ -146,6 +147,8 @@ static int run_one(const vk_op& o, int i, vk_stream_t s) {
                     case VK_FN_RELU_BWD: rc = vk_relu_bwd_bf16(g->p[0], g->p[1], g->p[2], g->n[0], s); break;
                     case VK_FN_COPY: rc = vk_copy_async(g->p[0], g->p[1], g->n[0], s); break;
                     case VK_FN_SUM_SLABS_BF16: rc = vk_sum_slabs_bf16(g->p[0], (const float*)g->p[1], g->n[0], (int)g->n[1], g->n[2], (const int32_t*)g->p[2], (int)g->n[3], s); break;
+                    case VK_FN_QUANT_ROWS: rc = vk_quant_rows_fp8(g->p[0], (int)g->n[4], g->n[2], g->p[1], g->n[3], (float*)g->p[2], (int)g->n[0], (int)g->n[1], (const int32_t*)g->p[3], s); break;
+                    case VK_FN_CAST_FP8: rc = vk_cast_bf16_fp8(g->p[0], g->p[1], g->n[0], g->f[0], s); break;
                     case VK_FN_SIDE_TAIL: rc = vk_side_tail((const vk_tail_job*)g->p[0], (int)g->n[0], s); break;
                     case VK_FN_SUM_SLABS: rc = vk_sum_slabs_f32((float*)g->p[0], (const float*)g->p[1], g->n[0], (int)g->n[1], g->n[2], s); break;
                     default: rc = vk::set_error("vk_run_ops: unknown generic fn %d at op %d", g->fn, i);

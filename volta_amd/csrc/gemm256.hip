@@ -372,7 +372,9 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
 // vmcnt counts loads and stores together in issue order: the next tile's prologue loads are OLDER than the epilogue's stores, so the
 // loop's first `vmcnt(8)` (all but the 8 youngest operations done) covers them -- conservatively, it also waits for most stores.
 template <bool AT, bool BT, int EPI, int TJ>
-__global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int total) {
+__global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int total, unsigned long long* const stamps) {
+    // `stamps` (study builds; NULL in the shipped library's launches): per workgroup and tile four s_memrealtime readings (100 MHz) --
+    // loop top, K loop done, ring drained + next prologue issued, epilogue done -- into a buffer no other code reads.
     static_assert(!(AT && BT), "the persistent kernel serves the NT / NN layouts (no bias-gradient accumulators)");
     constexpr int RING = 5;
     constexpr int BN = 64 * TJ, WN = 16 * TJ;
@@ -422,6 +424,9 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned long long* const st = stamps ? stamps + ((size_t)blockIdx.x * 8 + (size_t)((v - (int)blockIdx.x) / (int)gridDim.x)) * 4 : nullptr;
+        const bool stamping = st != nullptr && tid == 0 && (v - (int)blockIdx.x) / (int)gridDim.x < 8;
+        if (stamping) st[0] = __builtin_amdgcn_s_memrealtime();
         VK_WAIT_DMA();
         VK_SYNC();
         if (wr == 1) VK_SYNC();        // the upper half of the workgroup runs half a phase behind
@@ -450,6 +455,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int
             wrs = wrs == RING - 1 ? 0 : wrs + 1;
         }
         if (wr == 0) VK_SYNC();
+        if (stamping) st[1] = __builtin_amdgcn_s_memrealtime();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // retire the zero-fill stages issued past the end of K
         VK_SYNC();                                            // ... of every wave: the whole ring is free
 
@@ -460,13 +466,21 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int
             setup(nv);
             stage(0, 0); stage(1, 1); stage(2, 2);
         }
+        if (stamping) st[2] = __builtin_amdgcn_s_memrealtime();
         f32x4 accb[8];
         gemm_epilogue<AT, EPI, 8, TJ, (int)EPI_REGION>(g.p[cpi], acc, accb, false, cm0 + wr * 128, cn0 + wc * WN, g.p[cpi].M, lane,
                                                        lds0 + EPI_BASE + (uint32_t)wave * EPI_REGION);
+        if (stamping) st[3] = __builtin_amdgcn_s_memrealtime();
         if (!more) break;
         v = nv;
     }
 }
+
+#ifdef VK_STUDY
+static unsigned long long* g_stamps = nullptr;          // tools/stamp_gemm.py: where the persistent kernel writes its phase stamps
+#else
+static constexpr unsigned long long* g_stamps = nullptr;
+#endif
 
 template <bool AT, bool BT, int KSPLIT>      // 4 / 3 / 2: K-split kernel with 256 / 192 / 128 columns; 0: 4-phase 256 x 256 (study builds)
 static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s, bool persistent) {
@@ -482,7 +496,7 @@ static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s, boo
             if (persistent) {                                                                             \
                 auto kp = gemm256p_kernel<AT, BT, E, KSPLIT>;                                             \
                 static const hipError_t attr_p = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); (void)attr_p; \
-                hipLaunchKernelGGL(kp, dim3(total < NUM_CU ? total : NUM_CU), dim3(512), LDS, s, g, total); \
+                hipLaunchKernelGGL(kp, dim3(total < NUM_CU ? total : NUM_CU), dim3(512), LDS, s, g, total, g_stamps); \
                 break;                                                                                    \
             }                                                                                             \
         }                                                                                                 \
@@ -520,3 +534,7 @@ int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStre
 }
 
 }  // namespace vk
+
+#ifdef VK_STUDY
+extern "C" void vk_gemm_set_stamp_buffer(void* p) { vk::g_stamps = (unsigned long long*)p; }
+#endif

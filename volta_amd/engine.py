@@ -80,6 +80,9 @@ class ParamArena:
                 p.data = v
                 p.grad = None
         self.shadow_version = -1
+        self.weights_epoch = 0          # bumped whenever the master weights changed (torch-side edits, fused AdamW)
+        self.fp8_sites = {}             # data_ptr of an fp32 master view -> (view [N, K], q uint8 [N, Kp], scale [N])
+        self.fp8_epoch = -1
 
     def view(self, name, which="master"):
         buf = getattr(self, which)
@@ -128,9 +131,30 @@ class ParamArena:
         if force or self.shadow_version != v:
             check(L.lib.vk_cast_f32_bf16(ptr(self.master), ptr(self.shadow), self.total, L.stream_ptr()))
             self.shadow_version = v
+            self.weights_epoch += 1
 
     def mark_shadow_fresh(self):
         self.shadow_version = self.param_version()
+        self.weights_epoch += 1
+
+    def fp8_weight(self, w):
+        """e4m3 copy (+ per-output-channel scales) of the fp32 master weight view `w` [N, K], registered for refresh_fp8()."""
+        key = w.data_ptr()
+        if key not in self.fp8_sites:
+            N, K = w.shape
+            Kp = _round_up(K, 128)
+            self.fp8_sites[key] = (w, torch.zeros(N, Kp, dtype=torch.uint8, device=self.device), torch.ones(N, dtype=torch.float32, device=self.device))
+            self.fp8_epoch = -1
+        return self.fp8_sites[key][1:]
+
+    def refresh_fp8(self):
+        """Re-quantise the registered weights from the fp32 masters when they changed (one row kernel per weight matrix)."""
+        if self.fp8_epoch == self.weights_epoch:
+            return
+        for w, q, sc in self.fp8_sites.values():
+            N, K = w.shape
+            check(L.lib.vk_quant_rows_fp8(ptr(w), 1, w.stride(0), ptr(q), q.stride(0), ptr(sc), N, K, None, L.stream_ptr()))
+        self.fp8_epoch = self.weights_epoch
 
     def invalidate_shadow(self):
         self.shadow_version = -1
@@ -192,11 +216,16 @@ class Stream:
 class StepEngine:
     """Buffers + forward / backward command lists of one (B, T, Rv, train) shape."""
 
-    def __init__(self, cfg, arena, B, T, Rv, train, heads="pretrain"):
-        """heads: "pretrain" = the three pre-training heads and losses (BertForVLPreTraining); "tasks" = poolers only, the
+    H8_MUL = 8.0           # static scale of the fp8 copy of the GELU output: |h| <= 56 representable, 2^-9 absolute resolution near 0
+
+    def __init__(self, cfg, arena, B, T, Rv, train, heads="pretrain", fp8=False):
+        """fp8: the forward Q|K|V, FFN-up and FFN-down projections of every sub-layer run on the e4m3 MFMA path (csrc/fp8.hip); inputs are
+        quantised per row right before the GEMM, weights per output channel whenever they change; the backward stays bf16.
+        heads: "pretrain" = the three pre-training heads and losses (BertForVLPreTraining); "tasks" = poolers only, the
         sequence and pooled outputs leave the engine and their gradients enter it (BertForVLTasks)."""
         self.cfg, self.arena, self.B, self.T, self.Rv, self.train = cfg, arena, B, T, Rv, train
         self.heads = heads
+        self.fp8 = bool(fp8)
         dev = arena.device
         self.dev = dev
         H, Hv = cfg.hidden_size, cfg.v_hidden_size
@@ -268,6 +297,28 @@ class StepEngine:
     def prob(self, A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, C2=None, bias_grad=None, dyn=None, n_store=0):
         return L.GemmProblem(_addr(A), _addr(B), _addr(Cout), _addr(C2), _addr(bias), _addr(R), _addr(bias_grad), _addr(dyn),
                              M, N, K, lda, ldb, ldc, ldr, n_store)
+
+    def gemm_fp8(self, plan_ops, epi, specs):
+        """specs: [(A bf16 [M, K] or (A8, scale_a) already quantised, master weight view [N, K], C, bias, C2)] -- one fp8 launch for all of
+        them, preceded by the row quantisation of every bf16 A."""
+        probs = []
+        for idx, (A, Wm, Cout, bias, C2) in enumerate(specs):
+            w8, ws = self.arena.fp8_weight(Wm)
+            N, K = Wm.shape
+            if isinstance(A, tuple):
+                a8, sa = A
+                M = a8.shape[0]
+            else:
+                M = A.shape[0]
+                a8 = self.tmp("fp8_a%d_%d_%d" % (idx, M, K), (M, _round_up(K, 128)), torch.uint8)      # consumed by the launch that follows: shared by all sub-layers
+                if K % 128:
+                    a8[:, K:].zero_()               # the K padding is multiplied into the product: it must be zero, not stale bytes
+                sa = self.tmp("fp8_sa%d_%d_%d" % (idx, M, K), (M,), torch.float32)
+                plan_ops.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_QUANT_ROWS, p=(A, a8, sa, None), n=(M, K, A.stride(0), a8.stride(0), 0)), None, None))
+            probs.append(L.GemmFp8Problem(L.GemmProblem(_addr(a8), _addr(w8), _addr(Cout), _addr(C2), _addr(bias), None, None, None,
+                                                        M, N, K, a8.stride(0), w8.stride(0), Cout.stride(0), 0, 0), _addr(sa), _addr(ws)))
+        arr = self.k((L.GemmFp8Problem * len(probs))(*probs))
+        plan_ops.append((L.OP_GEMM_FP8, 0, epi, len(probs), arr, None, None))
 
     def generic(self, fn, p=(), n=(), f=(), drop=None):
         g = L.GenericArgs()
@@ -705,7 +756,10 @@ class StepEngine:
             nm = names[m]
             return self.arena.span([nm["q"] + ".bias", nm["k"] + ".bias", nm["v"] + ".bias"], which, (3 * H,))
 
-        self.gemm(f, L.NT, L.EPI_BF16, [self.prob(x_in[m], wqkv(m, "shadow"), qkv[m], self.st[m].M, 3 * H, H, H, H, 3 * H, bias=bqkv(m, "master")) for m in ms])
+        if self.fp8:
+            self.gemm_fp8(f, L.EPI_BF16, [(x_in[m], wqkv(m, "master"), qkv[m], bqkv(m, "master"), None) for m in ms])
+        else:
+            self.gemm(f, L.NT, L.EPI_BF16, [self.prob(x_in[m], wqkv(m, "shadow"), qkv[m], self.st[m].M, 3 * H, H, H, H, 3 * H, bias=bqkv(m, "master")) for m in ms])
         aa = L.AttnArgs()
         for m in ms:
             base = qkv[m].data_ptr()
@@ -782,8 +836,20 @@ class StepEngine:
         y = {m: self.buf(tag + "y%d" % m, (self.st[m].M, H)) for m in ms}
         mean = {m: self.buf(tag + "mean%d" % m, (self.st[m].M,), torch.float32) for m in ms}
         rstd = {m: self.buf(tag + "rstd%d" % m, (self.st[m].M,), torch.float32) for m in ms}
-        self.gemm(f, L.NT, L.EPI_GELU, [self.prob(x_in[m], self.W(names[m]["up"] + ".weight"), h[m], self.st[m].M, I, H, H, H, I, bias=self.Pm(names[m]["up"] + ".bias"), C2=gp[m]) for m in ms])
-        self.gemm(f, L.NT, L.EPI_BF16, [self.prob(h[m], self.W(names[m]["down"] + ".weight"), d[m], self.st[m].M, H, I, I, I, H, bias=self.Pm(names[m]["down"] + ".bias")) for m in ms])
+        if self.fp8:
+            self.gemm_fp8(f, L.EPI_GELU, [(x_in[m], self.Pm(names[m]["up"] + ".weight"), h[m], self.Pm(names[m]["up"] + ".bias"), gp[m]) for m in ms])
+            specs = []
+            for m in ms:        # the GELU output crosses to e4m3 with one static scale (elementwise pass), de-quantised through scale_a = 1 / mul
+                Mm = self.st[m].M
+                h8 = self.tmp("fp8_h%d_%d" % (m, Mm), (Mm, I), torch.uint8)
+                if "fp8_hscale_%d" % Mm not in self.bufs:
+                    self.bufs["fp8_hscale_%d" % Mm] = torch.full((Mm,), 1.0 / self.H8_MUL, dtype=torch.float32, device=self.dev)
+                f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_CAST_FP8, p=(h[m], h8), n=(Mm * I,), f=(self.H8_MUL,)), None, None))
+                specs.append(((h8, self.bufs["fp8_hscale_%d" % Mm]), self.Pm(names[m]["down"] + ".weight"), d[m], self.Pm(names[m]["down"] + ".bias"), None))
+            self.gemm_fp8(f, L.EPI_BF16, specs)
+        else:
+            self.gemm(f, L.NT, L.EPI_GELU, [self.prob(x_in[m], self.W(names[m]["up"] + ".weight"), h[m], self.st[m].M, I, H, H, H, I, bias=self.Pm(names[m]["up"] + ".bias"), C2=gp[m]) for m in ms])
+            self.gemm(f, L.NT, L.EPI_BF16, [self.prob(h[m], self.W(names[m]["down"] + ".weight"), d[m], self.st[m].M, H, I, I, I, H, bias=self.Pm(names[m]["down"] + ".bias")) for m in ms])
         odrop, lnf = {}, []
         for m in ms:
             odrop[m] = self.drop(cfg.hidden_dropout_prob if m == 0 else cfg.v_hidden_dropout_prob)

@@ -287,14 +287,21 @@ class BertForVLPreTraining(PreTrainedModel):
     def _engine(self, B, T, Rv, train):
         from .engine import StepEngine
         arena = self.materialize()
-        key = (B, T, Rv, bool(train))
+        fp8 = bool(self.__dict__.get("_fp8", False))
+        key = (B, T, Rv, bool(train), fp8)
         eng = self._engines.get(key)
         if eng is None:
             for k in [k for k in self._engines if k[3] == key[3]]:      # one plan per mode keeps memory bounded
                 del self._engines[k]
-            eng = StepEngine(self.config, arena, B, T, Rv, train, heads=getattr(self, "_heads_mode", "pretrain"))
+            eng = StepEngine(self.config, arena, B, T, Rv, train, heads=getattr(self, "_heads_mode", "pretrain"), fp8=fp8)
             self._engines[key] = eng
         return eng
+
+    def set_projection_dtype(self, dtype):
+        """"bf16" (default) or "fp8": run the forward Q|K|V / FFN projections of the encoder on the e4m3 MFMA path (csrc/fp8.hip)."""
+        if dtype not in ("bf16", "fp8"):
+            raise ValueError("projection dtype %r (bf16 | fp8)" % (dtype,))
+        self.__dict__["_fp8"] = dtype == "fp8"
 
     def _prep_inputs(self, input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask,
                      masked_lm_labels, image_label, image_cls, next_sentence_label):
@@ -330,6 +337,8 @@ class BertForVLPreTraining(PreTrainedModel):
         Rv = tensors["image_feat"].shape[1]
         eng = self._engine(B, T, Rv, self.training)
         eng.arena.refresh_shadow()
+        if eng.fp8:
+            eng.arena.refresh_fp8()
         eng.bind_inputs(tensors)
         if self._seed_base is None:
             self.__dict__["_seed_base"] = int(torch.initial_seed())
@@ -476,6 +485,7 @@ class BertForVLTasks(PreTrainedModel):
     _backward_begin = BertForVLPreTraining._backward_begin
     _backward_run = BertForVLPreTraining._backward_run
     set_dropout_seed = BertForVLPreTraining.set_dropout_seed
+    set_projection_dtype = BertForVLPreTraining.set_projection_dtype
 
     def __init__(self, config, task_cfg, task_ids, dropout_prob=0.1):
         super().__init__(config)
