@@ -348,8 +348,10 @@ int vk_memset_async(void* p, int value, int64_t bytes, vk_stream_t s);
 typedef struct vk_tail_job {
     float* dst;             /* kind 0: destination [n]; kind 1: dgamma [H] */
     float* dst2;            /* kind 1: dbeta [H] */
-    const float* src;       /* kind 0: slabs, slab s at src + s * stride; kind 1: partial records [rows][2][H] */
-    int64_t stride;         /* kind 0: elements between slabs (multiple of 4) */
+    const float* src;       /* kind 0: slabs, slab s at src + s * stride; kind 1: partial records [count][2][H] */
+    const float* src2;      /* kind 1: a second set of partial records [count2][2][H] summed into the same dgamma / dbeta (one LayerNorm
+                               shared by the text and the vision stream of a sub-layer), or NULL */
+    int64_t stride;         /* kind 0: elements between slabs (multiple of 4); kind 1: count2 */
     int64_t n;              /* kind 0: elements; kind 1: H */
     int32_t kind, count;    /* count: slabs (kind 0) / partial records (kind 1) */
     int32_t accumulate;     /* kind 1: dgamma / dbeta += */

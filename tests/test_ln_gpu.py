@@ -66,12 +66,16 @@ def test_side_tail_matches_separate_reductions():
     big = torch.randn(4, 70000, device="cuda", generator=g)
     d0, d1 = torch.zeros(1002, device="cuda"), torch.zeros(70000, device="cuda")
     dg, db = torch.ones(H, device="cuda"), torch.ones(H, device="cuda")
-    jobs = (L.TailJob * 3)(L.TailJob(d0.data_ptr(), None, slabs.data_ptr(), 1004, 1002, 0, 3, 0, 0),
-                           L.TailJob(dg.data_ptr(), db.data_ptr(), part.data_ptr(), 0, H, 1, rows, 1, 0),
-                           L.TailJob(d1.data_ptr(), None, big.data_ptr(), 70000, 70000, 0, 4, 0, 0))
-    L.check(L.lib.vk_side_tail(jobs, 3, L.stream_ptr()))
+    part2 = torch.randn(20, 2, H, device="cuda", generator=g)          # a second set of partial records for a shared LayerNorm
+    dg2, db2 = torch.zeros(H, device="cuda"), torch.zeros(H, device="cuda")
+    jobs = (L.TailJob * 4)(L.TailJob(d0.data_ptr(), None, slabs.data_ptr(), None, 1004, 1002, 0, 3, 0, 0),
+                           L.TailJob(dg.data_ptr(), db.data_ptr(), part.data_ptr(), None, 0, H, 1, rows, 1, 0),
+                           L.TailJob(d1.data_ptr(), None, big.data_ptr(), None, 70000, 70000, 0, 4, 0, 0),
+                           L.TailJob(dg2.data_ptr(), db2.data_ptr(), part.data_ptr(), part2.data_ptr(), 20, H, 1, rows, 0, 0))
+    L.check(L.lib.vk_side_tail(jobs, 4, L.stream_ptr()))
     torch.cuda.synchronize()
     want0 = sum(slabs[s * 1004:s * 1004 + 1002] for s in range(3))
     assert torch.allclose(d0, want0, atol=1e-5)
     assert torch.allclose(d1, big.sum(0), atol=1e-5)
     assert torch.allclose(dg, 1.0 + part[:, 0].sum(0), atol=1e-4) and torch.allclose(db, 1.0 + part[:, 1].sum(0), atol=1e-4)
+    assert torch.allclose(dg2, part[:, 0].sum(0) + part2[:, 0].sum(0), atol=1e-4) and torch.allclose(db2, part[:, 1].sum(0) + part2[:, 1].sum(0), atol=1e-4)

@@ -103,7 +103,7 @@ class AdamwArgs(C.Structure):
 
 
 class TailJob(C.Structure):
-    _fields_ = [("dst", c_p), ("dst2", c_p), ("src", c_p), ("stride", C.c_int64), ("n", C.c_int64), ("kind", i32), ("count", i32),
+    _fields_ = [("dst", c_p), ("dst2", c_p), ("src", c_p), ("src2", c_p), ("stride", C.c_int64), ("n", C.c_int64), ("kind", i32), ("count", i32),
                 ("accumulate", i32), ("block_start", i32)]
 
 

@@ -144,8 +144,11 @@ __global__ __launch_bounds__(256) void side_tail_kernel(const TailJobs t) {
         const int H = (int)J.n, tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
         const int i = blk * 16 + tx;
         float s = 0.f;
-        if (i < 2 * H)
+        if (i < 2 * H) {
             for (int b = ty; b < J.count; b += 16) s += J.src[(size_t)b * 2 * H + i];
+            if (J.src2)
+                for (int b = ty; b < (int)J.stride; b += 16) s += J.src2[(size_t)b * 2 * H + i];
+        }
         red[ty][tx] = s;
         __syncthreads();
         if (ty == 0 && i < 2 * H) {

@@ -916,9 +916,15 @@ class StepEngine:
         b.append((L.OP_SIDE_BEGIN, 0, 0, 0, None, None, None))
         self.gemm(b, L.TN, L.EPI_F32, probs)
         # every slab sum and every deferred LayerNorm dgamma / dbeta reduction of the sub-layer in ONE launch (vk_side_tail)
-        jobs = [L.TailJob(_addr(dst), None, _addr(src), stride, n, 0, ns, 0, 0) for dst, src, stride, ns, n in reduces]
-        for a in getattr(self, "_deferred_ln", []):          # LayerNorm parameter gradients of this sub-layer
-            jobs.append(L.TailJob(a.dgamma, a.dbeta, a.partial, 0, a.H, 1, L.lib.vk_ln_bwd_partial_rows(a.M), a.accumulate & 1, 0))
+        jobs = [L.TailJob(_addr(dst), None, _addr(src), None, stride, n, 0, ns, 0, 0) for dst, src, stride, ns, n in reduces]
+        by_dst = {}
+        for a in getattr(self, "_deferred_ln", []):          # LayerNorm parameter gradients of this sub-layer; a LayerNorm shared by both
+            by_dst.setdefault(a.dgamma, []).append(a)         # modalities has two sets of partial records: ONE job sums both (no ordering between jobs)
+        for group in by_dst.values():
+            assert len(group) <= 2 and not (group[0].accumulate & 1) and all(g.accumulate & 1 for g in group[1:]), "unexpected LayerNorm sharing"
+            a, b2 = group[0], (group[1] if len(group) > 1 else None)
+            jobs.append(L.TailJob(a.dgamma, a.dbeta, a.partial, b2.partial if b2 else None, L.lib.vk_ln_bwd_partial_rows(b2.M) if b2 else 0, a.H, 1,
+                                  L.lib.vk_ln_bwd_partial_rows(a.M), 0, 0))
         self._deferred_ln = []
         for i in range(0, len(jobs), L.TAIL_MAX_JOBS):
             chunk = jobs[i:i + L.TAIL_MAX_JOBS]
