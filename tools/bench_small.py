@@ -74,6 +74,10 @@ def concap(B=256, T=20, Rl=36, F=2048, Cn=1601):
 
 if __name__ == "__main__":
     import ctypes
+    if len(sys.argv) > 1 and sys.argv[1] == "ln":
+        for M in (5120, 9472, 14592):
+            ln(M)
+        sys.exit(0)
     if not (len(sys.argv) > 1 and sys.argv[1] == "fwd"):
         concap()
         ln(5120)
