@@ -251,159 +251,6 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const JobPair<vk_ln_
     }
 }
 
-// Backward, second form (H a multiple of 8): 16-byte accesses, HALF a wave (32 lanes, 8 elements per lane and chunk) per row, so a
-// wave works on two rows at a time; a workgroup covers 32 rows as two sub-blocks of LN_BWD_ROWS (waves 0-1 / 2-3: one partial record
-// each, so the record count stays vk_ln_bwd_partial_rows(M)); every wave walks its 8 rows in 4 steps with the NEXT step's dy / z
-// already requested (reads, arithmetic and the dz / dd stores of different steps overlap inside the wave instead of the whole grid
-// reading, then computing, then writing in lock-step: the first form ran at 2.8 TB/s on its 8 B/element).
-__device__ __forceinline__ float half_sum(float v) {      // over the 32 lanes of a half-wave
-#pragma unroll
-    for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
-}
-__device__ __forceinline__ void unpack8(const u32x4& w, float (&v)[8]) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { v[2 * r] = bf2f(w[r] & 0xFFFF); v[2 * r + 1] = bf2f(w[r] >> 16); }
-}
-
-template <int NCH>
-__global__ __launch_bounds__(256) void ln_bwd2_kernel(const JobPair<vk_ln_bwd_args> jp) {
-    __shared__ float red[2][2][NCH * 256];
-    const int nb0 = jp.nb0;
-    const bool second = (int)blockIdx.x >= nb0;
-    const vk_ln_bwd_args a = load_job<vk_ln_bwd_args>(second);
-    const int blk = second ? (int)blockIdx.x - nb0 : (int)blockIdx.x;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, hl = lane & 31;
-    const int sub = wave >> 1;
-    const int H = a.H;
-    const bool drop_on = a.drop.threshold != 0;
-    const uint64_t seed = drop_on ? *a.drop.seed : 0;
-    const int Mrows = a.dyn ? min(*a.dyn, a.M) : a.M;
-    const int row_base = blk * 32 + wave * 8;            // rows row_base + 2 * step + half
-    for (int i = threadIdx.x; i < 2 * 2 * NCH * 256; i += LN_THREADS) (&red[0][0][0])[i] = 0.f;
-
-    float pg[NCH][8], pb[NCH][8], gam[NCH][8];
-#pragma unroll
-    for (int j = 0; j < NCH; ++j) {
-        const int c = (j * 32 + hl) * 8;
-        f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0;
-        if (c < H) { g0 = *(const f32x4*)(a.gamma + c); g1 = *(const f32x4*)(a.gamma + c + 4); }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) { gam[j][r] = g0[r]; gam[j][4 + r] = g1[r]; }
-#pragma unroll
-        for (int r = 0; r < 8; ++r) pg[j][r] = pb[j][r] = 0.f;
-    }
-    u32x4 ady[NCH], az[NCH], bdy[NCH], bz[NCH];          // two named buffers (statically indexed): the row being worked on and the next one
-    auto request = [&](int step, u32x4 (&dyv)[NCH], u32x4 (&zv)[NCH]) {
-        const int row = row_base + 2 * step + half;
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int c = (j * 32 + hl) * 8;
-            dyv[j] = u32x4{0u, 0u, 0u, 0u};
-            zv[j] = u32x4{0u, 0u, 0u, 0u};
-            if (row < Mrows && c < H) {
-                dyv[j] = *(const u32x4*)((const uint16_t*)a.dy + (size_t)row * H + c);
-                zv[j] = *(const u32x4*)((const uint16_t*)a.z + (size_t)row * H + c);
-            }
-        }
-    };
-    auto process = [&](int step, const u32x4 (&cdy)[NCH], const u32x4 (&cz)[NCH]) {
-        const int row = row_base + 2 * step + half;
-        const bool live = row < Mrows;
-        const int rr = live ? row : 0;
-        uint32_t dsite;
-        const uint32_t drow = drop_row(a.seg, a.split_row, rr, dsite);
-        DropCfg dcfg{a.drop.seed, dsite, a.drop.threshold, a.drop.scale};
-        const float mean = a.mean[rr], rstd = a.rstd[rr];
-        uint32_t keep[NCH];                                  // bit e: element e of the chunk survives the dropout
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int j = 0; j < NCH; ++j) {
-            const int c = (j * 32 + hl) * 8;
-            keep[j] = 0xFFu;
-            if (drop_on && c < H) {
-                const u32x4 w0 = drop_words(dcfg, seed, drow, (uint32_t)(c >> 2)), w1 = drop_words(dcfg, seed, drow, (uint32_t)(c >> 2) + 1u);
-                keep[j] = 0u;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    keep[j] |= (w0[r] >= a.drop.threshold ? 1u : 0u) << r;
-                    keep[j] |= (w1[r] >= a.drop.threshold ? 1u : 0u) << (4 + r);
-                }
-            }
-            float dv[8], zv[8];
-            unpack8(cdy[j], dv);
-            unpack8(cz[j], zv);
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-                float gy = dv[r] * a.out_scale;
-                if (drop_on && a.post) gy = ((keep[j] >> r) & 1u) ? gy * a.drop.scale : 0.f;
-                const float xv = (zv[r] - mean) * rstd;
-                if (live && c < H) { pg[j][r] += gy * xv; pb[j][r] += gy; }
-                const float gx = gy * gam[j][r];
-                s1 += gx;
-                s2 += gx * xv;
-            }
-            __builtin_amdgcn_sched_barrier(0);           // one chunk at a time: interleaving the chunks keeps 3x the temporaries alive
-        }
-        s1 = half_sum(s1) / (float)H;
-        s2 = half_sum(s2) / (float)H;
-        if (live) {
-            uint16_t* dz = (uint16_t*)a.dz + (size_t)row * H;
-            uint16_t* dd = a.dd ? (uint16_t*)a.dd + (size_t)row * H : nullptr;
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int c = (j * 32 + hl) * 8;
-                if (c < H) {
-                    float dv[8], zv[8], o[8];
-                    u32x4 wdy = cdy[j], wz = cz[j];
-                    asm volatile("" : "+v"(wdy), "+v"(wz));      // opaque copies: recompute the 6 operations per element here instead of keeping
-                    unpack8(wdy, dv);                             // 32 more values per chunk alive across the row reductions
-                    unpack8(wz, zv);
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        float gy = dv[r] * a.out_scale;
-                        if (drop_on && a.post) gy = ((keep[j] >> r) & 1u) ? gy * a.drop.scale : 0.f;
-                        const float xv = (zv[r] - mean) * rstd;
-                        o[r] = rstd * (gy * gam[j][r] - s1 - xv * s2);
-                    }
-                    *(u32x4*)(dz + c) = u32x4{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
-                    if (dd) {
-                        if (drop_on && !a.post) {
-#pragma unroll
-                            for (int r = 0; r < 8; ++r) o[r] = ((keep[j] >> r) & 1u) ? o[r] * a.drop.scale : 0.f;
-                        }
-                        *(u32x4*)(dd + c) = u32x4{pack2bf(o[0], o[1]), pack2bf(o[2], o[3]), pack2bf(o[4], o[5]), pack2bf(o[6], o[7])};
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-    };
-    request(0, ady, az);
-#pragma unroll 1
-    for (int pair = 0; pair < 2; ++pair) {               // not unrolled: the compiler would hoist all four steps' loads (256 VGPRs)
-        request(2 * pair + 1, bdy, bz);
-        process(2 * pair, ady, az);
-        if (pair == 0) request(2, ady, az);
-        process(2 * pair + 1, bdy, bz);
-    }
-    // column partials of the sub-block's 4 half-waves: LDS float adds, then one [2][H] record per sub-block
-    __syncthreads();                // the zero fill of `red`
-#pragma unroll
-    for (int j = 0; j < NCH; ++j)
-#pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            atomicAdd(&red[sub][0][(j * 32 + hl) * 8 + r], pg[j][r]);
-            atomicAdd(&red[sub][1][(j * 32 + hl) * 8 + r], pb[j][r]);
-        }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 2 * 2 * NCH * 256; i += LN_THREADS) {
-        const int sb = i / (2 * NCH * 256), rem = i - sb * 2 * NCH * 256;
-        const int which = rem / (NCH * 256), c = rem - which * NCH * 256;
-        if (c < H && (blk * 32 + sb * LN_BWD_ROWS) < a.M) a.partial[((size_t)(blk * 2 + sb) * 2 + which) * H + c] = red[sb][which][c];
-    }
-}
-
 // column sums of the per-workgroup partial records: 64 columns x 16 row groups per workgroup
 __global__ __launch_bounds__(1024) void ln_bwd_finalize_kernel(const float* partial, int nblk, int H, float* dgamma, float* dbeta, int accumulate) {
     __shared__ float red[16][64];
@@ -474,17 +321,7 @@ extern "C" int vk_ln_bwd_pair(const vk_ln_bwd_args* a, const vk_ln_bwd_args* b, 
     jp.job[0] = *a;
     jp.job[1] = b ? *b : *a;
     jp.nb0 = nb0;
-    if (a->H % 8 == 0) {            // 16-byte form: blocks of 32 rows (two records each)
-        const int h0 = a->M > 0 ? (a->M + 31) / 32 : 0, h1 = (b && b->M > 0) ? (b->M + 31) / 32 : 0;
-        jp.nb0 = h0;
-        const dim3 grid2(h0 + h1);
-        switch (nch) {
-            case 1: hipLaunchKernelGGL(ln_bwd2_kernel<1>, grid2, block, 0, s, jp); break;
-            case 2: hipLaunchKernelGGL(ln_bwd2_kernel<2>, grid2, block, 0, s, jp); break;
-            case 3: hipLaunchKernelGGL(ln_bwd2_kernel<3>, grid2, block, 0, s, jp); break;
-            default: hipLaunchKernelGGL(ln_bwd2_kernel<4>, grid2, block, 0, s, jp); break;
-        }
-    } else switch (nch) {
+    switch (nch) {
         case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, jp); break;
         case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, jp); break;
         case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, jp); break;
