@@ -94,6 +94,9 @@ typedef struct vk_gemm_fp8_problem {
     vk_gemm_problem p;        /* R, bias_grad unused */
     const float* scale_a;     /* [M] or NULL */
     const float* scale_b;     /* [N] or NULL */
+    void* c8;                 /* VK_EPI_GELU only: e4m3 copy of C, c8[m, n] = saturate(C[m, n] * c8_mul), row stride ldc8 bytes; or NULL */
+    float c8_mul;
+    int32_t ldc8;
 } vk_gemm_fp8_problem;
 int vk_gemm_fp8_grouped(int epilogue, const vk_gemm_fp8_problem* probs, int nprob, int geometry, vk_stream_t s);
 /* Row-wise e4m3 quantisation: scale[m] = max|x[m,:]| / 448 (1 for a zero row), dst[m,k] = rne(x[m,k] / scale[m]); src bf16 (or fp32),
@@ -133,6 +136,9 @@ typedef struct vk_ln_args {
     float out_scale;       /* normally 1 (LXMERT image embedding: 0.5)                            */
     vk_dropout drop;       /* seed / threshold / scale; drop.site is ignored, see seg[]           */
     vk_drop_rows seg[2];
+    void* y8;              /* optional e4m3 copy of y, quantised per row (fp8 projection path): [M, ld8] bytes, or NULL */
+    float* y8_scale;       /* [M] de-quantisation factors: y[m, :] ~ y8[m, :] * y8_scale[m]                              */
+    int64_t ld8;           /* row stride of y8 in bytes (multiple of 8)                                                   */
 } vk_ln_args;
 int vk_ln_fwd(const vk_ln_args* a, vk_stream_t s);
 /* Two independent jobs of equal H in ONE launch (text and vision stream of a sub-layer); b may be NULL. */

@@ -216,3 +216,50 @@ def test_ctrl_vlbert_100_regions_fp8_against_reference_fixture(golden_dir):
     print(name, "fp8", {k: float("%.3g" % v) for k, v in report.items()})
     assert report["loss_lm"] <= FP8_LOSS_TOL and report["loss_img"] <= FP8_LOSS_TOL and report["loss_nsp"] <= 0.1, report       # ITM: 2 samples
     assert report["seq_t"] <= 0.15, report          # 24 sub-layers of fp8 projections
+
+
+def test_ln_fwd_writes_row_quantised_copy():
+    """vk_ln_fwd with y8 / y8_scale: the LayerNorm output leaves the kernel a second time as e4m3 rows (the next projection's A operand)."""
+    L, ops = _mods()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, H = 333, 768
+    d, x = (torch.randn(M, H, device="cuda", generator=g).bfloat16() for _ in range(2))
+    gamma, beta = 1 + 0.1 * torch.randn(H, device="cuda", generator=g), 0.1 * torch.randn(H, device="cuda", generator=g)
+    y, z = (torch.empty(M, H, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+    mean, rstd = torch.empty(M, device="cuda"), torch.empty(M, device="cuda")
+    y8 = torch.zeros(M, H, dtype=torch.uint8, device="cuda")
+    s8 = torch.zeros(M, device="cuda")
+    drop = L.dropout_cfg(None, 0, 0.0)
+    a = L.LnArgs(L.ptr(d), L.ptr(x), None, L.ptr(gamma), L.ptr(beta), L.ptr(y), L.ptr(z), L.ptr(mean), L.ptr(rstd), None, M, H, M, 0, 1.0, drop, ops._segs(drop, None))
+    a.y8, a.y8_scale, a.ld8 = y8.data_ptr(), s8.data_ptr(), H
+    L.check(L.lib.vk_ln_fwd(C.byref(a), ops.stream_ptr()))
+    torch.cuda.synchronize()
+    yf = y.float()
+    amax = yf.abs().amax(1)
+    assert torch.allclose(s8, amax / 448.0, rtol=1e-2)                 # the scale is taken before the bf16 rounding of y
+    deq = dequant(y8, s8, H)
+    assert float((deq - yf).abs().max() / yf.abs().max()) < 0.07
+    assert float((deq - yf).norm() / yf.norm()) < 0.04
+
+
+def test_gelu_epilogue_writes_static_scale_fp8_copy():
+    L, ops = _mods()
+    g = torch.Generator(device="cuda").manual_seed(9)
+    M, N, K, mul = 700, 3072, 768, 8.0
+    x = torch.randn(M, K, device="cuda", generator=g).bfloat16()
+    w = (torch.randn(N, K, device="cuda", generator=g) * 0.04).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g) * 0.1
+    qa, sa = quant_rows(L, ops, x)
+    qb, sb = quant_rows(L, ops, w)
+    h, gp = (torch.zeros(M, N, device="cuda", dtype=torch.bfloat16) for _ in range(2))
+    h8 = torch.zeros(M, N, dtype=torch.uint8, device="cuda")
+    p = L.GemmFp8Problem(L.GemmProblem(L.ptr(qa), L.ptr(qb), L.ptr(h), L.ptr(gp), L.ptr(bias), None, None, None, M, N, K, qa.stride(0), qb.stride(0), N, 0, 0),
+                         L.ptr(sa), L.ptr(sb), h8.data_ptr(), mul, N)
+    for geometry in (128, 256):
+        h8.zero_()
+        L.check(L.lib.vk_gemm_fp8_grouped(L.EPI_GELU, (L.GemmFp8Problem * 1)(p), 1, geometry, ops.stream_ptr()))
+        torch.cuda.synchronize()
+        deq = h8.cpu().view(torch.float8_e4m3fn).float().cuda() / mul
+        hf = h.float()
+        assert float(((deq - hf).abs() - (0.07 * hf.abs() + 2.0 ** -9 / mul + 4e-3)).clamp(min=0).max()) == 0.0     # e4m3 rounding (+ h's own bf16 rounding)
+        assert float((deq - hf).norm() / hf.norm()) < 0.04

@@ -45,7 +45,7 @@ class GemmProblem(C.Structure):
 
 
 class GemmFp8Problem(C.Structure):
-    _fields_ = [("p", GemmProblem), ("scale_a", c_p), ("scale_b", c_p)]
+    _fields_ = [("p", GemmProblem), ("scale_a", c_p), ("scale_b", c_p), ("c8", c_p), ("c8_mul", C.c_float), ("ldc8", i32)]
 
 
 GEMM_FP8_MAX_GROUP = 4
@@ -58,7 +58,7 @@ class DropRows(C.Structure):
 class LnArgs(C.Structure):
     _fields_ = [("d", c_p), ("x", c_p), ("addvec", c_p), ("gamma", c_p), ("beta", c_p), ("y", c_p), ("z", c_p),
                 ("mean", c_p), ("rstd", c_p), ("dyn", c_p), ("M", i32), ("H", i32), ("split_row", i32), ("post", i32),
-                ("out_scale", C.c_float), ("drop", Dropout), ("seg", DropRows * 2)]
+                ("out_scale", C.c_float), ("drop", Dropout), ("seg", DropRows * 2), ("y8", c_p), ("y8_scale", c_p), ("ld8", C.c_int64)]
 
 
 class LnBwdArgs(C.Structure):

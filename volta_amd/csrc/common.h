@@ -23,6 +23,16 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {      // one v_
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2{lo, hi}, bf16x2_t));
 }
 
+// four fp32 -> four OCP e4m3 bytes (round to nearest even, saturating at +-448)
+__device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d) {
+    a = __builtin_amdgcn_fmed3f(a, -448.0f, 448.0f); b = __builtin_amdgcn_fmed3f(b, -448.0f, 448.0f);
+    c = __builtin_amdgcn_fmed3f(c, -448.0f, 448.0f); d = __builtin_amdgcn_fmed3f(d, -448.0f, 448.0f);
+    uint32_t w = 0;
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
+    return w;
+}
+
 // ---- wave reductions (64 lanes) -------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -20,15 +20,6 @@ constexpr float FP8_MAX = 448.0f;          // largest finite e4m3fn
 struct KProb8 { KProb b; const float* sa; const float* sb; };
 struct KGroup8 { int32_t nprob; int32_t plain_order; KProb8 p[VK_GEMM_FP8_MAX_GROUP]; };
 
-__device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d) {
-    a = __builtin_amdgcn_fmed3f(a, -FP8_MAX, FP8_MAX); b = __builtin_amdgcn_fmed3f(b, -FP8_MAX, FP8_MAX);      // out-of-range values saturate
-    c = __builtin_amdgcn_fmed3f(c, -FP8_MAX, FP8_MAX); d = __builtin_amdgcn_fmed3f(d, -FP8_MAX, FP8_MAX);
-    uint32_t w = 0;
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, w, false);
-    w = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
-    return w;
-}
-
 // ---- quantisation ---------------------------------------------------------------------------------------------------------------
 // one wave per row: amax, scale = amax / 448 (1 for an all-zero row), q = round-to-nearest-even(x / scale); 8 elements per lane and step
 template <typename SRC>
@@ -227,6 +218,7 @@ extern "C" int vk_gemm_fp8_grouped(int epilogue, const vk_gemm_fp8_problem* prob
         if ((q.K % 128) != 0 && q.lda < ((q.K + 127) / 128) * 128) return set_error("vk_gemm_fp8_grouped: K=%d needs lda padded to a multiple of 128", q.K);
         if (q.bias_grad || q.R) return set_error("vk_gemm_fp8_grouped: forward epilogues only");
         if (epilogue == VK_EPI_GELU && !q.C2) return set_error("vk_gemm_fp8_grouped: C2 missing");
+        if (probs[i].c8 && (epilogue != VK_EPI_GELU || (probs[i].ldc8 & 3) || ((uintptr_t)probs[i].c8 & 3))) return set_error("vk_gemm_fp8_grouped: c8 is a GELU-epilogue output with a 4-byte aligned leading dimension");
         if ((uint64_t)q.M * q.lda >= 0x7FFFFFF0ull || (uint64_t)q.N * q.ldb >= 0x7FFFFFF0ull) return set_error("vk_gemm_fp8_grouped: operands must stay below 2 GiB");
         any_dyn |= q.dyn != nullptr;
     }
@@ -248,6 +240,7 @@ extern "C" int vk_gemm_fp8_grouped(int epilogue, const vk_gemm_fp8_problem* prob
         k.tiles_n = (ncols + edge - 1) / edge;
         k.tile_start = total;
         total += ((q.M + edge - 1) / edge) * k.tiles_n;
+        k.C8 = (char*)probs[i].c8; k.c8_mul = probs[i].c8_mul; k.ldc8 = probs[i].ldc8;
         g.p[i].sa = probs[i].scale_a; g.p[i].sb = probs[i].scale_b;
     }
     if (total == 0) return 0;

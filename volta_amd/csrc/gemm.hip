@@ -311,7 +311,7 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
         const vk_gemm_problem& q = probs[i];
         KProb& k = g.p[i];
         k.A = (const char*)q.A; k.B = (const char*)q.B; k.C = (char*)q.C; k.C2 = (char*)q.C2; k.bias = q.bias;
-        k.R = (const char*)q.R; k.bias_grad = q.bias_grad; k.dyn = q.dyn;
+        k.R = (const char*)q.R; k.bias_grad = q.bias_grad; k.dyn = q.dyn; k.C8 = nullptr; k.c8_mul = 0.f; k.ldc8 = 0;
         k.M = q.M; k.N = q.N; k.K = q.K; k.lda = q.lda; k.ldb = q.ldb; k.ldc = q.ldc; k.ldr = q.ldr; k.n_store = q.n_store;
         const int ncols = (f32out && q.n_store > q.N) ? q.n_store : q.N;
         k.tiles_n = (ncols + bn - 1) / bn;

@@ -14,6 +14,7 @@ struct KProb {
     const int32_t* dyn;
     int32_t M, N, K, lda, ldb, ldc, ldr, n_store;
     int32_t tiles_n, tile_start;
+    char* C8; float c8_mul; int32_t ldc8;      // GELU epilogue (fp8 path): e4m3 copy of C, q = saturate(C * c8_mul); NULL otherwise
 };
 constexpr int GROUP_PLAIN_ORDER = 1 << 16;    // KGroup::stagger flag: workgroup i takes tile i (no XCD chunking)
 struct KGroup {
@@ -154,6 +155,8 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
                     else o[r] = fmaxf(v[r], 0.f);
                 }
                 const u32x2 pk = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                if (EPI == VK_EPI_GELU && P.C8)        // fp8 copy for the FFN-down projection: 4 bytes per lane, straight from the registers
+                    *(uint32_t*)(P.C8 + (size_t)m * P.ldc8 + (size_t)(n_base + j * 16 + gq * 4)) = pack4_fp8(o[0] * P.c8_mul, o[1] * P.c8_mul, o[2] * P.c8_mul, o[3] * P.c8_mul);
                 if (via_lds) {
                     const uint32_t a = lrow * PITCH + (((j * 2 + (gq >> 1)) ^ (lrow & SWZ)) << 4) + ((gq & 1) << 3);
                     *(u32x2 VK_LDS*)(uintptr_t)(lds_region + a) = pk;
@@ -262,6 +265,14 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
             }
             if (!row_ok || n >= nlim) continue;
             uint16_t* c = (uint16_t*)P.C + off;
+            if (EPI == VK_EPI_GELU && P.C8) {
+                uint8_t* c8 = (uint8_t*)P.C8 + (size_t)m * P.ldc8 + n;
+                const uint32_t w8 = pack4_fp8(o[0] * P.c8_mul, o[1] * P.c8_mul, o[2] * P.c8_mul, o[3] * P.c8_mul);
+                if (full) *(uint32_t*)c8 = w8;
+                else
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) if (n + r < N) c8[r] = (uint8_t)(w8 >> (8 * r));
+            }
             if (full) {
                 *(u32x2*)c = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
                 if (EPI == VK_EPI_GELU) *(u32x2*)((uint16_t*)P.C2 + off) = u32x2{pack2bf(o2[0], o2[1]), pack2bf(o2[2], o2[3])};

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const JobPair<vk_ln_
     if (lane == 0) { a.mean[row] = mean; a.rstd[row] = rstd; }
     uint16_t* y = (uint16_t*)a.y + (size_t)row * H;
     uint16_t* zs = a.z ? (uint16_t*)a.z + (size_t)row * H : nullptr;
+    float amax = 0.f;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int c = j * 256 + lane * 4;
@@ -135,6 +136,21 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const JobPair<vk_ln_
             for (int r = 0; r < 4; ++r) o[r] *= a.out_scale;
             if (zs) store4(zs + c, z[j]);
             store4(y + c, o);
+            if (a.y8) {                    // keep the outputs (z is dead now) for the row-wise e4m3 copy
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { z[j][r] = o[r]; amax = fmaxf(amax, fabsf(o[r])); }
+            }
+        }
+    }
+    if (a.y8) {        // fp8 projection path: the consumer GEMM's A operand leaves this kernel already quantised (vk_quant_rows_fp8 semantics)
+        amax = wave_max(amax);
+        const float sc = amax > 0.f ? amax / 448.0f : 1.0f, inv = 1.0f / sc;
+        if (lane == 0) a.y8_scale[row] = sc;
+        uint8_t* q = (uint8_t*)a.y8 + (size_t)row * a.ld8;
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = j * 256 + lane * 4;
+            if (c < H) *(uint32_t*)(q + c) = pack4_fp8(z[j][0] * inv, z[j][1] * inv, z[j][2] * inv, z[j][3] * inv);
         }
     }
 }

@@ -302,7 +302,9 @@ class StepEngine:
         """specs: [(A bf16 [M, K] or (A8, scale_a) already quantised, master weight view [N, K], C, bias, C2)] -- one fp8 launch for all of
         them, preceded by the row quantisation of every bf16 A."""
         probs = []
-        for idx, (A, Wm, Cout, bias, C2) in enumerate(specs):
+        for idx, spec in enumerate(specs):
+            A, Wm, Cout, bias, C2 = spec[:5]
+            c8 = spec[5] if len(spec) > 5 else None            # (h8 uint8 [M, N], multiplier): e4m3 copy of the GELU output
             w8, ws = self.arena.fp8_weight(Wm)
             N, K = Wm.shape
             if isinstance(A, tuple):
@@ -316,7 +318,8 @@ class StepEngine:
                 sa = self.tmp("fp8_sa%d_%d_%d" % (idx, M, K), (M,), torch.float32)
                 plan_ops.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_QUANT_ROWS, p=(A, a8, sa, None), n=(M, K, A.stride(0), a8.stride(0), 0)), None, None))
             probs.append(L.GemmFp8Problem(L.GemmProblem(_addr(a8), _addr(w8), _addr(Cout), _addr(C2), _addr(bias), None, None, None,
-                                                        M, N, K, a8.stride(0), w8.stride(0), Cout.stride(0), 0, 0), _addr(sa), _addr(ws)))
+                                                        M, N, K, a8.stride(0), w8.stride(0), Cout.stride(0), 0, 0), _addr(sa), _addr(ws),
+                                          _addr(c8[0]) if c8 else None, c8[1] if c8 else 0.0, c8[0].stride(0) if c8 else 0))
         arr = self.k((L.GemmFp8Problem * len(probs))(*probs))
         plan_ops.append((L.OP_GEMM_FP8, 0, epi, len(probs), arr, None, None))
 
@@ -332,10 +335,22 @@ class StepEngine:
         g.drop = drop or L.dropout_cfg(None, 0, 0.0)
         return self.k(g)
 
-    def ln_args(self, d, x, gname, bname, y, z, mean, rstd, M, drop, post=0, out_scale=1.0, addvec=None, dyn=None, segs=None):
+    def ln_args(self, d, x, gname, bname, y, z, mean, rstd, M, drop, post=0, out_scale=1.0, addvec=None, dyn=None, segs=None, fp8_out=None):
+        """fp8_out = (q uint8 [M, ld8], scale fp32 [M]): the kernel also leaves a row-quantised e4m3 copy of y (the next projection's A operand)."""
         a = L.LnArgs(_addr(d), _addr(x), _addr(addvec), _addr(self.Pm(gname)), _addr(self.Pm(bname)), _addr(y), _addr(z), _addr(mean),
                      _addr(rstd), _addr(dyn), M, self.H, M, post, out_scale, drop, _mk_segs(drop, segs))
+        if fp8_out is not None:
+            a.y8, a.y8_scale, a.ld8 = _addr(fp8_out[0]), _addr(fp8_out[1]), fp8_out[0].stride(0)
         return self.k(a)
+
+    def fp8_hidden(self, m):
+        """Per-modality e4m3 copy of the current hidden state, written by the LayerNorm that produces it and read by the next
+        sub-layer's first projection (one buffer per modality: consumed before the next LayerNorm of that modality runs)."""
+        M, H = self.st[m].M, self.H
+        q = self.tmp("fp8_x%d" % m, (M, _round_up(H, 128)), torch.uint8)
+        if H % 128:
+            q.zero_()
+        return q, self.tmp("fp8_xs%d" % m, (M,), torch.float32)
 
     def ln_bwd_args(self, dy, z, mean, rstd, gname, bname, dz, dd, M, drop, post=0, out_scale=1.0, dyn=None, segs=None, accumulate=0, defer=False):
         """`defer`: the dgamma / dbeta column reduction is left to an OP_LN_FINALIZE that the next _wgrad() places in its
@@ -366,6 +381,7 @@ class StepEngine:
             self.patch(name, g, "p", 0)
             f.append((L.OP_GENERIC, 0, 0, 0, g, None, None))
         self.x = [None, None]        # current hidden state buffers
+        self.x8 = [None, None]       # fp8 path: (e4m3 copy, row scales) of x[m] when its producer wrote one
         self.level = [0, 0]          # number of sub-layers that transformed x[m] so far (ping-pong parity of dX)
         self.bwd_pro = []            # zero-fills of gradient tensors that are accumulated with atomics
         kind = cfg.image_embeddings
@@ -740,6 +756,7 @@ class StepEngine:
         ms = [m for m in range(2) if act[m]]
         tag = "L%d_" % n
         x_in = list(self.x)
+        x8_in = list(self.x8)
         qkv = {m: self.buf(tag + "qkv%d" % m, (self.st[m].M, 3 * H)) for m in ms}
         ctx = {m: self.buf(tag + "ctx%d" % m, (self.st[m].M, H)) for m in ms}
         lse = {m: self.buf(tag + "lse%d" % m, (B * nh * self.st[m].L,), torch.float32) for m in ms}
@@ -757,7 +774,7 @@ class StepEngine:
             return self.arena.span([nm["q"] + ".bias", nm["k"] + ".bias", nm["v"] + ".bias"], which, (3 * H,))
 
         if self.fp8:
-            self.gemm_fp8(f, L.EPI_BF16, [(x_in[m], wqkv(m, "master"), qkv[m], bqkv(m, "master"), None) for m in ms])
+            self.gemm_fp8(f, L.EPI_BF16, [(x8_in[m] or x_in[m], wqkv(m, "master"), qkv[m], bqkv(m, "master"), None) for m in ms])
         else:
             self.gemm(f, L.NT, L.EPI_BF16, [self.prob(x_in[m], wqkv(m, "shadow"), qkv[m], self.st[m].M, 3 * H, H, H, H, 3 * H, bias=bqkv(m, "master")) for m in ms])
         aa = L.AttnArgs()
@@ -788,7 +805,9 @@ class StepEngine:
         odrop, lnf = {}, []
         for m in ms:
             odrop[m] = self.drop(cfg.hidden_dropout_prob if m == 0 else cfg.v_hidden_dropout_prob)
-            lnf.append(self.ln_args(d[m], x_in[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", y[m], d[m], mean[m], rstd[m], self.st[m].M, odrop[m]))
+            self.x8[m] = self.fp8_hidden(m) if self.fp8 else None
+            lnf.append(self.ln_args(d[m], x_in[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", y[m], d[m], mean[m], rstd[m], self.st[m].M, odrop[m],
+                                    fp8_out=self.x8[m]))
             self.x[m] = y[m]
         f.append((L.OP_LN_FWD, 0, 0, 0, lnf[0], lnf[1] if len(lnf) > 1 else None, None))      # both streams in one launch
         # ------------- backward
@@ -830,6 +849,7 @@ class StepEngine:
         ms = [m for m in range(2) if act[m]]
         tag = "L%d_" % n
         x_in = list(self.x)
+        x8_in = list(self.x8)
         h = {m: self.buf(tag + "h%d" % m, (self.st[m].M, I)) for m in ms}
         gp = {m: self.buf(tag + "gp%d" % m, (self.st[m].M, I)) for m in ms}
         d = {m: self.buf(tag + "z%d" % m, (self.st[m].M, H)) for m in ms}
@@ -837,15 +857,17 @@ class StepEngine:
         mean = {m: self.buf(tag + "mean%d" % m, (self.st[m].M,), torch.float32) for m in ms}
         rstd = {m: self.buf(tag + "rstd%d" % m, (self.st[m].M,), torch.float32) for m in ms}
         if self.fp8:
-            self.gemm_fp8(f, L.EPI_GELU, [(x_in[m], self.Pm(names[m]["up"] + ".weight"), h[m], self.Pm(names[m]["up"] + ".bias"), gp[m]) for m in ms])
-            specs = []
-            for m in ms:        # the GELU output crosses to e4m3 with one static scale (elementwise pass), de-quantised through scale_a = 1 / mul
+            # the GELU output also leaves the epilogue as e4m3 with one static scale (the FFN-down projection's A operand), de-quantised
+            # there through scale_a = 1 / multiplier
+            up, specs = [], []
+            for m in ms:
                 Mm = self.st[m].M
                 h8 = self.tmp("fp8_h%d_%d" % (m, Mm), (Mm, I), torch.uint8)
                 if "fp8_hscale_%d" % Mm not in self.bufs:
                     self.bufs["fp8_hscale_%d" % Mm] = torch.full((Mm,), 1.0 / self.H8_MUL, dtype=torch.float32, device=self.dev)
-                f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_CAST_FP8, p=(h[m], h8), n=(Mm * I,), f=(self.H8_MUL,)), None, None))
+                up.append((x8_in[m] or x_in[m], self.Pm(names[m]["up"] + ".weight"), h[m], self.Pm(names[m]["up"] + ".bias"), gp[m], (h8, self.H8_MUL)))
                 specs.append(((h8, self.bufs["fp8_hscale_%d" % Mm]), self.Pm(names[m]["down"] + ".weight"), d[m], self.Pm(names[m]["down"] + ".bias"), None))
+            self.gemm_fp8(f, L.EPI_GELU, up)
             self.gemm_fp8(f, L.EPI_BF16, specs)
         else:
             self.gemm(f, L.NT, L.EPI_GELU, [self.prob(x_in[m], self.W(names[m]["up"] + ".weight"), h[m], self.st[m].M, I, H, H, H, I, bias=self.Pm(names[m]["up"] + ".bias"), C2=gp[m]) for m in ms])
@@ -853,7 +875,9 @@ class StepEngine:
         odrop, lnf = {}, []
         for m in ms:
             odrop[m] = self.drop(cfg.hidden_dropout_prob if m == 0 else cfg.v_hidden_dropout_prob)
-            lnf.append(self.ln_args(d[m], x_in[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", y[m], d[m], mean[m], rstd[m], self.st[m].M, odrop[m]))
+            self.x8[m] = self.fp8_hidden(m) if self.fp8 else None
+            lnf.append(self.ln_args(d[m], x_in[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", y[m], d[m], mean[m], rstd[m], self.st[m].M, odrop[m],
+                                    fp8_out=self.x8[m]))
             self.x[m] = y[m]
         f.append((L.OP_LN_FWD, 0, 0, 0, lnf[0], lnf[1] if len(lnf) > 1 else None, None))      # both streams in one launch
         b = []
