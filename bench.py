@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--seq-len", type=int, default=20)
     ap.add_argument("--regions", type=int, default=36)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp8"], help="arithmetic of the projection GEMMs (fp8: forward projections on the MX-scaled fp8 MFMA, bf16 elsewhere)")
+    ap.add_argument("--no-opt-overlap", action="store_true", help="AdamW as one launch on the compute stream instead of range by range under the next forward")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--serial", action="store_true", help="run the side-stream blocks (weight gradients) inline: per-kernel profiles without concurrency")
@@ -253,7 +254,7 @@ def main():
     no_decay = ("bias", "LayerNorm.bias", "LayerNorm.weight")
     groups = [{"params": [p], "lr": 1e-4, "weight_decay": 0.0 if any(nd in n for nd in no_decay) else 0.01}
               for n, p in model.named_parameters()]                       # one group per parameter (train_concap.py:213-224)
-    opt = AdamW(groups, lr=1e-4, eps=1e-6, betas=(0.9, 0.999))
+    opt = AdamW(groups, lr=1e-4, eps=1e-6, betas=(0.9, 0.999), overlap_with_forward=not a.no_opt_overlap)
     sched = WarmupLinearSchedule(opt, warmup_steps=100, t_total=100000)
     batch = synthetic_batch(cfg, a.batch, a.seq_len, a.regions, seed=1234 + rank)
     args = model_args(batch)

@@ -129,6 +129,7 @@ class ParamArena:
         counter: in-place edits through `p.data` (`p.data.mul_()`): call invalidate_shadow() after those."""
         v = self.param_version()
         if force or self.shadow_version != v:
+            self.sync_optimizer()
             check(L.lib.vk_cast_f32_bf16(ptr(self.master), ptr(self.shadow), self.total, L.stream_ptr()))
             self.shadow_version = v
             self.weights_epoch += 1
@@ -158,6 +159,15 @@ class ParamArena:
 
     def invalidate_shadow(self):
         self.shadow_version = -1
+
+    def sync_optimizer(self):
+        """Make the current stream wait for a pipelined optimizer step still in flight on its own stream."""
+        pend = getattr(self, "opt_pending", None)
+        if pend:
+            cur = torch.cuda.current_stream()
+            for ev in pend[1]:
+                cur.wait_event(ev)
+            self.opt_pending = None
 
 
 # ======================================================================================== plan
@@ -408,13 +418,16 @@ class StepEngine:
         # its backward temporaries in buffer set k % 2 and records side event k % 8 after its wgrad; its backward
         # first waits for the event of sub-layer k + 2, the previous user of that buffer set.
         self.n_sub = len(list(sublayer_schedule(cfg)))
+        self.fwd_sub_start = []       # forward op index at which sub-layer k begins (the optimizer overlap cuts the list there)
         for k, (n, typ) in enumerate(sublayer_schedule(cfg)):
             self.sub_k = k
+            self.fwd_sub_start.append(len(self.fwd.ops))
             ops = self._attn_sublayer(n) if typ == "attn" else self._ffn_sublayer(n)
             if k + 2 < self.n_sub:
                 ops.insert(0, (L.OP_WAIT_SIDE, (k + 2) % 8, 0, 0, None, None, None))
             bwd_stages.append(ops)
             self.taps["t%d" % n], self.taps["v%d" % n] = self.x[0], self.x[1]
+        self.fwd_heads_start = len(self.fwd.ops)
         head_bwd = self._heads() if self.heads == "pretrain" else self._heads_tasks()
         # backward list: zero-fills, heads, then stages in reverse; bwd_marks[s] = op index at which backward
         # stage s is complete (stage 0 = heads), param_ready_stage[name] = stage after which its gradient is final
@@ -914,11 +927,19 @@ class StepEngine:
                 key = gW.data_ptr()
                 per_w.setdefault(key, (gW, gB, Mo, No, []))[4].append((dY, X, self.st[m].M, lda, ldb))
             jobs += list(per_w.values())
+        # K-chunk length: ~5120 rows, halved (down to ~1280) while the whole group still yields fewer than ~200 tiles of 256 x 256 -- the
+        # attention sub-layers' group ([768, 768] and [2304, 768] outputs) is 108 tiles of 150 K-steps at 5120, i.e. 42 % of the CUs
+        # busy for 127 us; more, shorter chunks fill the chip (the extra slabs cost the tail launch a few microseconds)
+        chunk_rows = float(os.environ.get('VK_WGRAD_CHUNK', '5120'))
+        if 'VK_WGRAD_CHUNK' not in os.environ:
+            tiles = lambda cr: sum(-(-Mo // 256) * -(-No // 256) * sum(max(1, int(round(rows / cr))) for _, _, rows, _, _ in srcs) for _, _, Mo, No, srcs in jobs)
+            while chunk_rows > 1280 and tiles(chunk_rows) < 200:
+                chunk_rows /= 2
         probs, reduces = [], []
         for gW, gB, Mo, No, srcs in jobs:
             chunks = []
             for dY, X, rows, lda, ldb in srcs:
-                ns = max(1, int(round(rows / float(os.environ.get('VK_WGRAD_CHUNK', '5120')))))
+                ns = max(1, int(round(rows / chunk_rows)))
                 step = -(-rows // ns)
                 step = -(-step // 64) * 64
                 r0 = 0
@@ -959,7 +980,7 @@ class StepEngine:
 
     def _slab(self, n):
         """fp32 workspace for split-K partials; one arena reused by every sub-layer (launches are stream-ordered)."""
-        cap = 40 * 3072 * 768
+        cap = 48 * 3072 * 768
         ws = self.tmp("wgrad_slabs", (cap,), torch.float32)
         cur = getattr(self, "_slab_cursor", 0)
         cur = _round_up(cur, 4)
@@ -1143,6 +1164,55 @@ class StepEngine:
         return b
 
     # ---------------------------------------------------------------- run
+    def fwd_segments(self, bounds):
+        """Cut the forward list for an optimizer that is still updating the arena in `bounds` = [chunk index where range r ends] (ranges in
+        arena order = forward order): [(ranges that must be complete, op start, op end)].  The embeddings need what lies before the first
+        encoder sub-layer, sub-layer n its own slots, the heads (poolers, cls.*, the tied decoder) everything."""
+        arena = self.arena
+        key = tuple(bounds)
+        cache = self.__dict__.setdefault("_fwd_segments", {})
+        if key in cache:
+            return cache[key]
+
+        def need(prefixes):          # number of leading ranges covering every parameter with one of these prefixes
+            hi = max((arena.offset[nm] + int(torch.tensor(arena.shape[nm]).prod()) for nm in arena.params if nm.startswith(tuple(prefixes))), default=0)
+            hi_chunk = -(-hi // CHUNK)
+            return next((i + 1 for i, b in enumerate(bounds) if b >= hi_chunk), len(bounds))
+
+        nemb = len(self.stage_prefix) - len(self.fwd_sub_start)
+        cuts = [(need(self.stage_prefix[0] if nemb else ["bert.embeddings."]), 0)]
+        for k, start in enumerate(self.fwd_sub_start):
+            cuts.append((need(self.stage_prefix[nemb + k]), start))
+        cuts.append((len(bounds), self.fwd_heads_start))
+        segs, cur_need = [], 0
+        for i, (nd, start) in enumerate(cuts):
+            end = cuts[i + 1][1] if i + 1 < len(cuts) else len(self.fwd.ops)
+            nd = max(nd, cur_need)                       # waits are cumulative
+            if segs and nd == cur_need:
+                segs[-1] = (nd, segs[-1][1], end)        # nothing new to wait for: extend the previous segment
+            else:
+                segs.append((nd, start, end))
+            cur_need = nd
+        cache[key] = segs
+        return segs
+
+    def run_forward(self):
+        """The forward list; when a pipelined optimizer (AdamW(overlap_with_forward=True)) is still walking the arena on its own stream,
+        every segment first waits for the ranges whose weights it reads."""
+        pend = getattr(self.arena, "opt_pending", None)
+        if not pend:
+            self.fwd.run()
+            return
+        bounds, events = pend
+        cur = torch.cuda.current_stream()
+        waited = 0
+        for nd, start, end in self.fwd_segments(bounds):
+            for i in range(waited, nd):
+                cur.wait_event(events[i])
+            waited = max(waited, nd)
+            self.fwd.run(start, end)
+        self.arena.opt_pending = None
+
     def bind_inputs(self, tensors):
         """Patch the per-step input pointers into the few ops that read user tensors."""
         self._cur_inputs = tensors

@@ -338,13 +338,14 @@ class BertForVLPreTraining(PreTrainedModel):
         eng = self._engine(B, T, Rv, self.training)
         eng.arena.refresh_shadow()
         if eng.fp8:
+            eng.arena.sync_optimizer()         # the re-quantisation reads the fp32 masters
             eng.arena.refresh_fp8()
         eng.bind_inputs(tensors)
         if self._seed_base is None:
             self.__dict__["_seed_base"] = int(torch.initial_seed())
         eng.prepare_step(self._seed_base + self._step)
         self.__dict__["_step"] += 1
-        eng.fwd.run()
+        eng.run_forward()
         self.__dict__["_last"] = (eng, tensors)      # keeps the step's input tensors alive until backward
         return getattr(eng, "losses", None)
 

@@ -53,7 +53,12 @@ def _check_shared_chunks(arena, included, what, among=None):
 
 
 class AdamW(Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-6, weight_decay=0.0, correct_bias=True, overlap_with_forward=False, overlap_ranges=8):
+        """overlap_with_forward: issue the update as `overlap_ranges` launches over consecutive arena ranges (= forward order) on a stream
+        of its own; the model's next forward waits range by range for the weights it is about to read, so the HBM-bound update of the late
+        layers runs under the MFMA-bound forward of the early ones.  Same arithmetic, same results.  Opt-in because host code that reads
+        parameters right after step() WITHOUT a device synchronisation (`p.cpu()` on the current stream) would race with that stream:
+        call `optimizer.synchronize()` (or torch.cuda.synchronize()) before such reads."""
         if lr < 0.0:
             raise ValueError("Invalid learning rate: {} - should be >= 0.0".format(lr))
         if not 0.0 <= betas[0] < 1.0:
@@ -64,6 +69,7 @@ class AdamW(Optimizer):
             raise ValueError("Invalid epsilon value: {} - should be >= 0.0".format(eps))
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
         self._fused = None
+        self._overlap = (bool(overlap_with_forward), int(overlap_ranges))
 
     def _setup(self):
         allp = [p for g in self.param_groups for p in g["params"]]
@@ -146,9 +152,45 @@ class AdamW(Optimizer):
         t = f["step"]
         a.step_mult = math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t) if g0["correct_bias"] else 1.0
         a.grad_scale = grad_scale
-        L.check(L.lib.vk_adamw_step(C.byref(a), L.stream_ptr()))
+        arena.sync_optimizer()         # an earlier pipelined step nobody waited for (two steps without a forward in between)
+        if not self._overlap[0]:
+            L.check(L.lib.vk_adamw_step(C.byref(a), L.stream_ptr()))
+        else:
+            self._step_pipelined(a, arena, clip)
         arena.mark_shadow_fresh()      # the kernel refreshed the bf16 copies itself
         return loss
+
+    def _step_pipelined(self, a, arena, clip):
+        f = self._fused
+        if "stream" not in f:
+            n = max(1, min(self._overlap[1], arena.total // 1024))
+            nchunks = arena.total // 1024
+            f["stream"] = torch.cuda.Stream(device=arena.device)
+            f["bounds"] = [nchunks * (i + 1) // n for i in range(n)]
+            f["events"] = [torch.cuda.Event() for _ in range(n)]
+        side, bounds, events = f["stream"], f["bounds"], f["events"]
+        side.wait_stream(torch.cuda.current_stream())          # gradients, their norm and the clip coefficient are final
+        if clip is not None:
+            clip.record_stream(side)
+        base = (a.p, a.g, a.m, a.v, a.shadow, a.chunk_class)
+        with torch.cuda.stream(side):
+            sp = C.c_void_p(side.cuda_stream)
+            lo = 0
+            for hi, ev in zip(bounds, events):
+                if hi > lo:
+                    off = lo * 1024
+                    a.p, a.g, a.m, a.v = base[0] + 4 * off, base[1] + 4 * off, base[2] + 4 * off, base[3] + 4 * off
+                    a.shadow, a.chunk_class = base[4] + 2 * off, base[5] + lo
+                    a.n = (hi - lo) * 1024
+                    L.check(L.lib.vk_adamw_step(C.byref(a), sp))
+                ev.record(side)
+                lo = hi
+        arena.opt_pending = (bounds, events)
+
+    def synchronize(self):
+        """Current stream waits for a pipelined step (needed only before host code reads parameters without a device sync)."""
+        if self._fused is not None:
+            self._fused["arena"].sync_optimizer()
 
     # ---- checkpoint interchange (volta/train_utils.py:295-340 saves optimizer.state_dict() of pytorch_transformers'
     # AdamW: per parameter {"step", "exp_avg", "exp_avg_sq"}, indexed in param_groups order)
@@ -166,6 +208,7 @@ class AdamW(Optimizer):
         return out
 
     def state_dict(self):
+        self.synchronize()
         sd = super().state_dict()
         if self._fused is not None and self._fused["step"] > 0:
             f = self._fused
@@ -174,6 +217,7 @@ class AdamW(Optimizer):
         return sd
 
     def load_state_dict(self, state_dict):
+        self.synchronize()
         state = state_dict.get("state", {})
         super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
         if not state:
