@@ -12,7 +12,7 @@ namespace vk {
 
 constexpr float LN_EPS = 1e-12f;
 constexpr int LN_THREADS = 256;
-constexpr int LN_BWD_ROWS = 16;     // rows per workgroup in the backward (4 per wave, all requested up front)
+constexpr int LN_BWD_ROWS = 32;     // rows per workgroup in the backward: 8 per wave in two passes of 4 (requested up front / as registers free up)
 
 // Philox row of `row` under the two-segment mapping of vk_ln_args.seg (see include/volta_hip.h)
 __device__ __forceinline__ uint32_t drop_row(const vk_drop_rows (&seg)[2], int split, int row, uint32_t& site) {
@@ -176,11 +176,14 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const JobPair<vk_ln_
     // Each wave owns LN_BWD_ROWS / 4 rows; the bf16 inputs of ALL of them are requested up front (raw 8-byte
     // loads, 2 VGPRs per 4 elements) so that several rows' worth of HBM latency overlap instead of being paid
     // one row after the other.
-    constexpr int RPW = LN_BWD_ROWS / 4;
+    // Two passes of 4 rows per wave.  Pass 0's rows are all requested up front; as soon as a row's raw registers have been unpacked,
+    // the same registers request the matching row of pass 1 -- so the second half's HBM latency runs under the first half's arithmetic
+    // and stores, and a 14592-row launch is ONE round of 1824 waves (at 16 rows per workgroup it was 3648 waves on 3072 slots: two
+    // rounds, the second one fifth full, 32 us for 18 us worth of bytes).
+    constexpr int RPW = 4, PASSES = LN_BWD_ROWS / (4 * RPW);
     u32x2 rdy[RPW][NCH], rz[RPW][NCH];
-#pragma unroll
-    for (int it = 0; it < RPW; ++it) {
-        const int row = blk * LN_BWD_ROWS + it * 4 + wave;
+    auto request = [&](int it, int pass) {
+        const int row = blk * LN_BWD_ROWS + pass * 16 + it * 4 + wave;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c = j * 256 + lane * 4;
@@ -191,11 +194,14 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const JobPair<vk_ln_
                 rz[it][j] = *(const u32x2*)((const uint16_t*)a.z + (size_t)row * H + c);
             }
         }
-    }
+    };
 #pragma unroll
-    for (int it = 0; it < RPW; ++it) {
-        const int row = blk * LN_BWD_ROWS + it * 4 + wave;
-        if (row >= Mrows) break;
+    for (int it = 0; it < RPW; ++it) request(it, 0);
+#pragma unroll
+    for (int pit = 0; pit < PASSES * RPW; ++pit) {
+        const int pass = pit / RPW, it = pit % RPW;
+        const int row = blk * LN_BWD_ROWS + pass * 16 + it * 4 + wave;
+        if (row >= Mrows) continue;
         uint32_t dsite;
         const uint32_t drow = drop_row(a.seg, a.split_row, row, dsite);
         DropCfg dcfg{a.drop.seed, dsite, a.drop.threshold, a.drop.scale};
@@ -229,6 +235,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const JobPair<vk_ln_
                 }
             }
         }
+        if (pass + 1 < PASSES) request(it, pass + 1);          // this row's raw registers are free: they fetch the next pass's row
         s1 = wave_sum(s1) / (float)H;
         s2 = wave_sum(s2) / (float)H;
         uint16_t* dz = (uint16_t*)a.dz + (size_t)row * H;
