@@ -34,15 +34,31 @@ __device__ __forceinline__ uint32_t pack4_fp8(float a, float b, float c, float d
 }
 
 // ---- wave reductions (64 lanes) -------------------------------------------------------------
+// DPP forms: four in-row steps (quad xor 1, quad xor 2, half-row mirror, row mirror: every lane of a 16-lane row ends with the row's
+// result), two cross-row broadcasts (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3: lane 63 holds the wave's result) and
+// one v_readlane -- ~8 VALU instructions instead of six dependent ds_bpermute round trips through the LDS crossbar (what __shfl_xor
+// compiles to), which is most of a LayerNorm row's latency.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float v, float old) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += dpp_move<0xB1, 0xF>(v, v);        // quad_perm [1,0,3,2]
+    v += dpp_move<0x4E, 0xF>(v, v);        // quad_perm [2,3,0,1]
+    v += dpp_move<0x141, 0xF>(v, v);       // row_half_mirror
+    v += dpp_move<0x140, 0xF>(v, v);       // row_mirror
+    v += dpp_move<0x142, 0xA>(v, 0.f);     // row_bcast:15 -> rows 1, 3
+    v += dpp_move<0x143, 0xC>(v, 0.f);     // row_bcast:31 -> rows 2, 3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, dpp_move<0xB1, 0xF>(v, v));
+    v = fmaxf(v, dpp_move<0x4E, 0xF>(v, v));
+    v = fmaxf(v, dpp_move<0x141, 0xF>(v, v));
+    v = fmaxf(v, dpp_move<0x140, 0xF>(v, v));
+    v = fmaxf(v, dpp_move<0x142, 0xA>(v, v));      // unmasked rows keep their own value: max is idempotent
+    v = fmaxf(v, dpp_move<0x143, 0xC>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 // ---- Philox-4x32: the engine's counter-based random streams ------------------------------------

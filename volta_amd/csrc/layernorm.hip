@@ -12,7 +12,9 @@ namespace vk {
 
 constexpr float LN_EPS = 1e-12f;
 constexpr int LN_THREADS = 256;
-constexpr int LN_BWD_ROWS = 32;     // rows per workgroup in the backward: 8 per wave in two passes of 4 (requested up front / as registers free up)
+constexpr int LN_BWD_ROWS = 16;     // rows per workgroup in the backward: 4 per wave, all requested up front (32 rows in two passes with the second pass
+                                    // requested as the first one's registers free up measured SLOWER, 38.6 vs ~32 us at 14592 rows: a wave's rows run
+                                    // one after the other, ~1 us each, and halving the wave count halves the rows in progress)
 
 // Philox row of `row` under the two-segment mapping of vk_ln_args.seg (see include/volta_hip.h)
 __device__ __forceinline__ uint32_t drop_row(const vk_drop_rows (&seg)[2], int split, int row, uint32_t& site) {
@@ -176,10 +178,6 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const JobPair<vk_ln_
     // Each wave owns LN_BWD_ROWS / 4 rows; the bf16 inputs of ALL of them are requested up front (raw 8-byte
     // loads, 2 VGPRs per 4 elements) so that several rows' worth of HBM latency overlap instead of being paid
     // one row after the other.
-    // Two passes of 4 rows per wave.  Pass 0's rows are all requested up front; as soon as a row's raw registers have been unpacked,
-    // the same registers request the matching row of pass 1 -- so the second half's HBM latency runs under the first half's arithmetic
-    // and stores, and a 14592-row launch is ONE round of 1824 waves (at 16 rows per workgroup it was 3648 waves on 3072 slots: two
-    // rounds, the second one fifth full, 32 us for 18 us worth of bytes).
     constexpr int RPW = 4, PASSES = LN_BWD_ROWS / (4 * RPW);
     u32x2 rdy[RPW][NCH], rz[RPW][NCH];
     auto request = [&](int it, int pass) {
