@@ -178,34 +178,36 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const JobPair<vk_ln_
     // Each wave owns LN_BWD_ROWS / 4 rows; the bf16 inputs of ALL of them are requested up front (raw 8-byte
     // loads, 2 VGPRs per 4 elements) so that several rows' worth of HBM latency overlap instead of being paid
     // one row after the other.
-    constexpr int RPW = 4, PASSES = LN_BWD_ROWS / (4 * RPW);
-    u32x2 rdy[RPW][NCH], rz[RPW][NCH];
-    auto request = [&](int it, int pass) {
-        const int row = blk * LN_BWD_ROWS + pass * 16 + it * 4 + wave;
+    // A wave owns 4 rows.  Two of them are in flight at any time: a row's raw registers request the row after next as soon as they
+    // have been unpacked (all four up front cost 154 VGPRs = 3 waves per SIMD, and 3648 waves on 3072 slots ran as two rounds with
+    // the second one fifth full; two in flight fit 4 waves per SIMD: one round).
+    constexpr int RPW = LN_BWD_ROWS / 4, PRE = 2;
+    u32x2 rdy[PRE][NCH], rz[PRE][NCH];
+    auto request = [&](int it, u32x2 (&dyv)[NCH], u32x2 (&zv)[NCH]) {
+        const int row = blk * LN_BWD_ROWS + it * 4 + wave;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c = j * 256 + lane * 4;
-            rdy[it][j] = u32x2{0u, 0u};
-            rz[it][j] = u32x2{0u, 0u};
-            if (row < Mrows && c < H) {
-                rdy[it][j] = *(const u32x2*)((const uint16_t*)a.dy + (size_t)row * H + c);
-                rz[it][j] = *(const u32x2*)((const uint16_t*)a.z + (size_t)row * H + c);
+            dyv[j] = u32x2{0u, 0u};
+            zv[j] = u32x2{0u, 0u};
+            if (it < RPW && row < Mrows && c < H) {
+                dyv[j] = *(const u32x2*)((const uint16_t*)a.dy + (size_t)row * H + c);
+                zv[j] = *(const u32x2*)((const uint16_t*)a.z + (size_t)row * H + c);
             }
         }
     };
 #pragma unroll
-    for (int it = 0; it < RPW; ++it) request(it, 0);
+    for (int it = 0; it < PRE; ++it) request(it, rdy[it], rz[it]);
 #pragma unroll
-    for (int pit = 0; pit < PASSES * RPW; ++pit) {
-        const int pass = pit / RPW, it = pit % RPW;
-        const int row = blk * LN_BWD_ROWS + pass * 16 + it * 4 + wave;
-        if (row >= Mrows) continue;
+    for (int it = 0; it < RPW; ++it) {
+        const int row = blk * LN_BWD_ROWS + it * 4 + wave;
+        if (row >= Mrows) break;
         uint32_t dsite;
         const uint32_t drow = drop_row(a.seg, a.split_row, row, dsite);
         DropCfg dcfg{a.drop.seed, dsite, a.drop.threshold, a.drop.scale};
         const float mean = a.mean[row], rstd = a.rstd[row];
         float xh[NCH][4], gh[NCH][4];
-        u32x4 words[NCH];
+        uint32_t keep[NCH];              // bit r: element r of the chunk survives the dropout (4 bits instead of the 4 Philox words)
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
@@ -213,15 +215,19 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const JobPair<vk_ln_
 #pragma unroll
             for (int r = 0; r < 4; ++r) xh[j][r] = gh[j][r] = 0.f;
             if (c < H) {
-                const u32x2 d2 = rdy[it][j], z2 = rz[it][j];
+                const u32x2 d2 = rdy[it % PRE][j], z2 = rz[it % PRE][j];
                 const float dv[4] = {bf2f(d2[0] & 0xFFFF), bf2f(d2[0] >> 16), bf2f(d2[1] & 0xFFFF), bf2f(d2[1] >> 16)};
                 const float zv[4] = {bf2f(z2[0] & 0xFFFF), bf2f(z2[0] >> 16), bf2f(z2[1] & 0xFFFF), bf2f(z2[1] >> 16)};
-                if (drop_on) words[j] = drop_words(dcfg, seed, drow, (uint32_t)(c >> 2));
+                keep[j] = 0xFu;
+                if (drop_on) {
+                    const u32x4 w = drop_words(dcfg, seed, drow, (uint32_t)(c >> 2));
+                    keep[j] = (w[0] >= a.drop.threshold ? 1u : 0u) | (w[1] >= a.drop.threshold ? 2u : 0u) | (w[2] >= a.drop.threshold ? 4u : 0u) | (w[3] >= a.drop.threshold ? 8u : 0u);
+                }
                 const f32x4 g = *(const f32x4*)(a.gamma + c);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     float gy = dv[r] * a.out_scale;
-                    if (drop_on && a.post) gy = (words[j][r] >= a.drop.threshold) ? gy * a.drop.scale : 0.f;
+                    if (drop_on && a.post) gy = ((keep[j] >> r) & 1u) ? gy * a.drop.scale : 0.f;
                     const float xv = (zv[r] - mean) * rstd;
                     pg[j][r] += gy * xv;
                     pb[j][r] += gy;
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const JobPair<vk_ln_
                 }
             }
         }
-        if (pass + 1 < PASSES) request(it, pass + 1);          // this row's raw registers are free: they fetch the next pass's row
+        request(it + PRE, rdy[it % PRE], rz[it % PRE]);        // this row's raw registers are free: they fetch the row after next
         s1 = wave_sum(s1) / (float)H;
         s2 = wave_sum(s2) / (float)H;
         uint16_t* dz = (uint16_t*)a.dz + (size_t)row * H;
@@ -249,7 +255,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const JobPair<vk_ln_
                 if (dd) {
                     if (drop_on && !a.post) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = (words[j][r] >= a.drop.threshold) ? o[r] * a.drop.scale : 0.f;
+                        for (int r = 0; r < 4; ++r) o[r] = ((keep[j] >> r) & 1u) ? o[r] * a.drop.scale : 0.f;
                     }
                     store4(dd + c, o);
                 }
