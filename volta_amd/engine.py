@@ -398,12 +398,26 @@ class StepEngine:
         bwd_stages = []
         nemb = 1 if kind in ("visualbert", "vl-bert") else 2
         self.stage_prefix = [["bert.embeddings.", "bert.v_embeddings."]] * nemb + [["bert.encoder.layer.%d." % n] for n, _ in sublayer_schedule(cfg)]
-        if kind == "vilbert":
+        # ViLBERT's first sub-layers are text-only (ctrl_vilbert_base: 0-11): the image embedding does not depend on them, nor they on it.
+        # Its forward runs on the executor's side stream next to them (joined before the first sub-layer that touches the vision
+        # stream), its backward likewise as soon as that sub-layer's backward has produced the vision gradient -- instead of at the very
+        # end of the list, after the text-only sub-layers, whose launches (240 tiles or fewer) leave CUs idle.
+        sched = list(sublayer_schedule(cfg))
+        uses_v = lambda n, typ: (n in cfg.tv_attn_sublayers or n in cfg.vt_attn_sublayers or n in cfg.vv_attn_sublayers) if typ == "attn" else n in cfg.v_ff_sublayers
+        k_vis = next((k for k, (n, typ) in enumerate(sched) if uses_v(n, typ)), len(sched))
+        emb_image_aside = kind in ("vilbert", "lxmert") and 0 < k_vis < len(sched)
+        emb_image_bwd = None
+        if kind in ("vilbert", "lxmert"):
             bwd_stages.append(self._emb_text("bert.embeddings."))
-            bwd_stages.append(self._emb_image_vilbert("bert.v_embeddings."))
-        elif kind == "lxmert":
-            bwd_stages.append(self._emb_text("bert.embeddings."))
-            bwd_stages.append(self._emb_image_lxmert("bert.v_embeddings."))
+            i0 = len(f)
+            img_bwd = (self._emb_image_vilbert if kind == "vilbert" else self._emb_image_lxmert)("bert.v_embeddings.")
+            if emb_image_aside:
+                f.insert(i0, (L.OP_SIDE_BEGIN, 0, 0, 0, None, None, None))
+                f.append((L.OP_SIDE_END, 15, 0, 0, None, None, None))
+                emb_image_bwd = [(L.OP_SIDE_BEGIN, 0, 0, 0, None, None, None)] + img_bwd + [(L.OP_SIDE_END, 14, 0, 0, None, None, None)]
+                bwd_stages.append([])
+            else:
+                bwd_stages.append(img_bwd)
         elif kind == "uniter":
             bwd_stages.append(self._emb_text("bert.embeddings."))
             bwd_stages.append(self._emb_image_uniter("bert.embeddings."))
@@ -419,12 +433,16 @@ class StepEngine:
         # first waits for the event of sub-layer k + 2, the previous user of that buffer set.
         self.n_sub = len(list(sublayer_schedule(cfg)))
         self.fwd_sub_start = []       # forward op index at which sub-layer k begins (the optimizer overlap cuts the list there)
-        for k, (n, typ) in enumerate(sublayer_schedule(cfg)):
+        for k, (n, typ) in enumerate(sched):
             self.sub_k = k
             self.fwd_sub_start.append(len(self.fwd.ops))
+            if emb_image_aside and k == k_vis:
+                f.append((L.OP_WAIT_SIDE, 15, 0, 0, None, None, None))       # the vision stream enters here: its embedding must be complete
             ops = self._attn_sublayer(n) if typ == "attn" else self._ffn_sublayer(n)
             if k + 2 < self.n_sub:
                 ops.insert(0, (L.OP_WAIT_SIDE, (k + 2) % 8, 0, 0, None, None, None))
+            if emb_image_aside and k == k_vis:
+                ops = ops + emb_image_bwd                                   # d(loss)/d(vision embedding) is final after this sub-layer's backward
             bwd_stages.append(ops)
             self.taps["t%d" % n], self.taps["v%d" % n] = self.x[0], self.x[1]
         self.fwd_heads_start = len(self.fwd.ops)
