@@ -503,6 +503,7 @@ class StepEngine:
                                    st.M, st.L, H, cfg.type_vocab_size, cfg.vocab_size, cfg.max_position_embeddings))
         self.patch("input_ids", eb, "ids")
         self.patch("token_type_ids", eb, "type_ids")
+        b.append((L.OP_WAIT_SIDE, 12, 0, 0, None, None, None))      # the tied LM decoder's weight gradient (heads, side stream) initialises the table's gradient
         b.append((L.OP_EMBED_BWD, 0, 0, 0, eb, None, None))
         return b
 
@@ -653,6 +654,7 @@ class StepEngine:
                                    cfg.max_position_embeddings))
         self.patch("input_ids", eb, "ids")
         self.patch("token_type_ids", eb, "type_ids")
+        b.append((L.OP_WAIT_SIDE, 12, 0, 0, None, None, None))      # after the tied LM decoder's weight gradient (heads, side stream)
         b.append((L.OP_EMBED_BWD, 0, 0, 0, eb, None, None))
         return b
 
@@ -737,6 +739,7 @@ class StepEngine:
                                    st_t.M, T, H, cfg.type_vocab_size, cfg.vocab_size, cfg.max_position_embeddings))
         self.patch("input_ids", eb, "ids")
         self.patch("token_type_ids", eb, "type_ids")
+        b.append((L.OP_WAIT_SIDE, 12, 0, 0, None, None, None))      # after the tied LM decoder's weight gradient (heads, side stream)
         b.append((L.OP_EMBED_BWD, 0, 0, 0, eb, None, None))
         dtv = self.buf("vl_dtv", (B, H))
         b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ROWGROUP_SUM, p=(dzt, dtv), n=(B, T, H)), None, None))
@@ -1047,7 +1050,8 @@ class StepEngine:
         xa = self.k(L.XentArgs(_addr(logits_t), None, _addr(pos_t), _addr(n_t), _addr(lse_t), _addr(self.sums[0:1]), V, Vp, st_t.M))
         self.patch("masked_lm_labels", xa, "labels")
         f.append((L.OP_XENT_FWD, 0, 0, 0, xa, None, None))
-        # ---- masked regions (kl_1601) on labelled rows
+        # ---- masked regions (kl_1601) on labelled rows: an independent chain of small launches -> side stream, joined before the loss finalisation
+        f.append((L.OP_SIDE_BEGIN, 0, 0, 0, None, None, None))
         Mr = B * R
         rows_v, pos_v = self.buf("rows_v", (Mr,), torch.int32), self.buf("pos_v", (Mr,), torch.int32)
         off = 1 if cfg.add_global_imgfeat == "first" else 0
@@ -1072,6 +1076,7 @@ class StepEngine:
         ka = self.k(L.KlArgs(_addr(logits_v), None, _addr(pos_v), _addr(n_v), _addr(lse_v), _addr(tsum_v), _addr(self.sums[1:2]), kw, Cn, Cp, Mr))
         self.patch("image_cls", ka, "target")
         f.append((L.OP_KL_FWD, 0, 0, 0, ka, None, None))
+        f.append((L.OP_SIDE_END, 11, 0, 0, None, None, None))
         # ---- ITM head (its dropout site is the last one of the forward pass)
         pooled = self.buf("pooled", (B, P))
         pdrop = self.drop(0.1)
@@ -1082,18 +1087,43 @@ class StepEngine:
         xi = self.k(L.XentArgs(_addr(itm), None, None, None, _addr(lse_i), _addr(self.sums[2:3]), 2, 64, B))
         self.patch("next_sentence_label", xi, "labels")
         f.append((L.OP_XENT_FWD, 0, 0, 0, xi, None, None))
+        f.append((L.OP_WAIT_SIDE, 11, 0, 0, None, None, None))
         f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_LOSS_FINAL, p=(self.sums, n_t, n_v, self.losses), n=(B,), f=(kw,)), None, None))
         self.taps.update(seq_t=x_t, seq_v=x_v, pooled_t=pt, pooled_v=pv)
 
-        # ================= backward of the heads: produces dX[0], dX[1] (buffer 'a')
-        b = []
+        # ================= backward of the heads: produces dX[0], dX[1] (buffer 'a').  Three independent chains of small launches:
+        # the masked-LM chain and the ITM chain stay on the caller's stream, the region chain (with its weight gradients) runs on the side
+        # stream next to them (event 13, awaited before the encoder's backward reads dX[1]), and every weight gradient of the two main
+        # chains follows in a second side block (event 12, awaited before the embedding backward adds to the word-embedding gradient
+        # that the tied LM decoder's weight gradient initialises).  Each chain has its own temporaries.
+        b, wg = [], []
         dxh = [self._dx(m, self.level[m] % 2) for m in range(2)]
         for m in range(2):
             b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MEMSET, p=(dxh[m],), n=(dxh[m].numel() * 2, 0)), None, None))
-        # LM
+        # ---- region chain (side stream)
+        b.append((L.OP_SIDE_BEGIN, 0, 0, 0, None, None, None))
+        dlog_v = self.buf("img_dlogits", (Mr, Cp))
+        b.append((L.OP_KL_BWD, Cp, 0, 0, ka, dlog_v, self.gout[1:2]))
+        dhn_v = self.tmp("head_v_d1", (Mr, H))
+        wdec = ci + "decoder_dict.0."
+        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dlog_v, self.W(wdec + "weight"), dhn_v, Mr, H, Cn, Cp, H, H, dyn=n_v)])
+        self.gemm(b, L.TN, L.EPI_F32, [self.prob(dlog_v, hn_v, self.G(wdec + "weight"), Cn, H, Mr, Cp, H, H, bias_grad=self.G(wdec + "bias"), dyn=n_v)])
+        if cfg.image_head_ln:
+            dhv = self.tmp("head_v_d2", (Mr, H))
+            b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dhn_v, hv, im_mean, im_rstd, ci + "transform.LayerNorm.weight", ci + "transform.LayerNorm.bias", dhv, None, Mr, nodrop, dyn=n_v), None, None))
+        else:
+            dhv = dhn_v
+        du_v = self.tmp("head_v_d3", (Mr, H))
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MUL, p=(dhv, gpv, du_v, n_v), n=(Mr * H, H)), None, None))
+        dhx_v = self.tmp("head_v_d2" if not cfg.image_head_ln else "head_v_d1", (Mr, H))
+        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(du_v, self.W(ci + "transform.dense.weight"), dhx_v, Mr, H, H, H, H, H, dyn=n_v)])
+        self.gemm(b, L.TN, L.EPI_F32, [self.prob(du_v, hx_v, self.G(ci + "transform.dense.weight"), H, H, Mr, H, H, H, bias_grad=self.G(ci + "transform.dense.bias"), dyn=n_v)])
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SCATTER_ADD, p=(dhx_v, rows_v, n_v, dxh[1]), n=(H, Mr)), None, None))
+        b.append((L.OP_SIDE_END, 13, 0, 0, None, None, None))
+        # ---- masked-LM chain
         dlog_t = self.buf("lm_dlogits", (st_t.M, Vp))
         b.append((L.OP_XENT_BWD, Vp, 0, 0, xa, dlog_t, self.gout[0:1]))
-        dhn_t = self.tmp("head_d1", (max(st_t.M, Mr), H))
+        dhn_t = self.tmp("head_d1", (st_t.M, H))
         # d(hidden) = dlogits[n_t, V] . E[V, H]: few rows, very long contraction -> split K over the vocabulary into
         # chunks written as fp32 slabs by one grouped launch, then summed (and rounded to bf16) in one pass
         nsplit = max(1, min(16, V // 1920))
@@ -1111,45 +1141,34 @@ class StepEngine:
                 k0 += kc
             self.gemm(b, L.NN, L.EPI_F32, probs)
             b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SUM_SLABS_BF16, p=(dhn_t, slabs, n_t), n=(stride, len(probs), stride, H)), None, None))
-        self.gemm(b, L.TN, L.EPI_F32, [self.prob(dlog_t, hn_t, self.G(wword), V, H, st_t.M, Vp, H, H, bias_grad=self.G(c + "bias"), dyn=n_t)])
-        dht = self.tmp("head_d2", (max(st_t.M, Mr), H))
+        self.gemm(wg, L.TN, L.EPI_F32, [self.prob(dlog_t, hn_t, self.G(wword), V, H, st_t.M, Vp, H, H, bias_grad=self.G(c + "bias"), dyn=n_t)])
+        dht = self.tmp("head_d2", (st_t.M, H))
         b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dhn_t, ht, lm_mean, lm_rstd, c + "transform.LayerNorm.weight", c + "transform.LayerNorm.bias", dht, None, st_t.M, nodrop, dyn=n_t), None, None))
-        du_t = self.tmp("head_d3", (max(st_t.M, Mr), H))
+        du_t = self.tmp("head_d3", (st_t.M, H))
         b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MUL, p=(dht, gpt, du_t, n_t), n=(st_t.M * H, H)), None, None))
-        dhx_t = self.tmp("head_d1", (max(st_t.M, Mr), H))
+        dhx_t = self.tmp("head_d1", (st_t.M, H))
         self.gemm(b, L.NN, L.EPI_BF16, [self.prob(du_t, self.W(c + "transform.dense.weight"), dhx_t, st_t.M, H, H, H, H, H, dyn=n_t)])
-        self.gemm(b, L.TN, L.EPI_F32, [self.prob(du_t, hx_t, self.G(c + "transform.dense.weight"), H, H, st_t.M, H, H, H, bias_grad=self.G(c + "transform.dense.bias"), dyn=n_t)])
+        self.gemm(wg, L.TN, L.EPI_F32, [self.prob(du_t, hx_t, self.G(c + "transform.dense.weight"), H, H, st_t.M, H, H, H, bias_grad=self.G(c + "transform.dense.bias"), dyn=n_t)])
         b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SCATTER_ADD, p=(dhx_t, rows_t, n_t, dxh[0]), n=(H, st_t.M)), None, None))
-        # image head
-        dlog_v = self.buf("img_dlogits", (Mr, Cp))
-        b.append((L.OP_KL_BWD, Cp, 0, 0, ka, dlog_v, self.gout[1:2]))
-        dhn_v = self.tmp("head_d1", (max(st_t.M, Mr), H))
-        wdec = ci + "decoder_dict.0."
-        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dlog_v, self.W(wdec + "weight"), dhn_v, Mr, H, Cn, Cp, H, H, dyn=n_v)])
-        self.gemm(b, L.TN, L.EPI_F32, [self.prob(dlog_v, hn_v, self.G(wdec + "weight"), Cn, H, Mr, Cp, H, H, bias_grad=self.G(wdec + "bias"), dyn=n_v)])
-        if cfg.image_head_ln:
-            dhv = self.tmp("head_d2", (max(st_t.M, Mr), H))
-            b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dhn_v, hv, im_mean, im_rstd, ci + "transform.LayerNorm.weight", ci + "transform.LayerNorm.bias", dhv, None, Mr, nodrop, dyn=n_v), None, None))
-        else:
-            dhv = dhn_v
-        du_v = self.tmp("head_d3", (max(st_t.M, Mr), H))
-        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MUL, p=(dhv, gpv, du_v, n_v), n=(Mr * H, H)), None, None))
-        dhx_v = self.tmp("head_d2" if not cfg.image_head_ln else "head_d1", (max(st_t.M, Mr), H))
-        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(du_v, self.W(ci + "transform.dense.weight"), dhx_v, Mr, H, H, H, H, H, dyn=n_v)])
-        self.gemm(b, L.TN, L.EPI_F32, [self.prob(du_v, hx_v, self.G(ci + "transform.dense.weight"), H, H, Mr, H, H, H, bias_grad=self.G(ci + "transform.dense.bias"), dyn=n_v)])
-        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SCATTER_ADD, p=(dhx_v, rows_v, n_v, dxh[1]), n=(H, Mr)), None, None))
-        # ITM
+        # ---- ITM chain
         dlog_i = self.buf("itm_dlogits", (B, 64))
         b.append((L.OP_XENT_BWD, 64, 0, 0, xi, dlog_i, self.gout[2:3]))
         dpooled = self.buf("d_pooled", (B, P))
         wi = "cls.bi_seq_relationship."
         self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dlog_i, self.W(wi + "weight"), dpooled, B, P, 2, 64, P, P)])
-        self.gemm(b, L.TN, L.EPI_F32, [self.prob(dlog_i, pooled, self.G(wi + "weight"), 2, P, B, 64, P, P, bias_grad=self.G(wi + "bias"))])
+        self.gemm(wg, L.TN, L.EPI_F32, [self.prob(dlog_i, pooled, self.G(wi + "weight"), 2, P, B, 64, P, P, bias_grad=self.G(wi + "bias"))])
         dyt, dyv = self.buf("d_pool_t", (B, P)), self.buf("d_pool_v", (B, P))
         b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_POOL_BWD, p=(dpooled, pt, pv, dyt, dyv), n=(B, P, P), drop=pdrop), None, None))
         for m, (dy_, xm, Lm, pre) in enumerate(((dyt, x_t, T, "bert.t_pooler.dense."), (dyv, x_v, Rv, "bert.v_pooler.dense."))):
+            # rows b * L: the first token of every sample -- disjoint from the labelled rows the region chain scatters into
             self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dy_, self.W(pre + "weight"), dxh[m], B, H, P, P, H, Lm * H, R=dxh[m], ldr=Lm * H)])
-            self.gemm(b, L.TN, L.EPI_F32, [self.prob(dy_, xm, self.G(pre + "weight"), P, H, B, P, Lm * H, H, bias_grad=self.G(pre + "bias"))])
+            self.gemm(wg, L.TN, L.EPI_F32, [self.prob(dy_, xm, self.G(pre + "weight"), P, H, B, P, Lm * H, H, bias_grad=self.G(pre + "bias"))])
+        # ---- the main chains' weight gradients, off the critical path
+        b.append((L.OP_SIDE_BEGIN, 0, 0, 0, None, None, None))
+        b += wg
+        b.append((L.OP_SIDE_END, 12, 0, 0, None, None, None))
+        b.append((L.OP_WAIT_SIDE, 13, 0, 0, None, None, None))            # dX[1] is complete
+        self._head_wgrad_event = 12
         return b
 
     def _heads_tasks(self):
