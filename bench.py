@@ -74,6 +74,18 @@ def _dev_int(addr, eng):
     raise KeyError(addr)
 
 
+def source_fingerprint():
+    """sha1 over the HIP / C++ sources of the library: ties a committed PMC summary to the kernels it measured."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "volta_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp")):
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()
+
+
 def usable_cpus():
     """Host cores this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU box shows all 256 host
     cores to a container that is granted a 16-CPU share; 256 torch threads on 16 CPUs run ~50x slower than 16)."""
@@ -350,11 +362,16 @@ def main():
             out["kernel_ms_per_step"] = {k: round(v, 3) for k, v in sorted(kinds.items(), key=lambda kv: -kv[1])}
             # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the figure is the
             # one of the committed rocprofv3 --pmc passes over this same command (profiles/r01_pmc_hbm_traffic.md)
-            pmc = os.path.join(ROOT, "profiles", "r01_pmc_summary.json")
-            if os.path.exists(pmc) and a.config == "ctrl_vilbert_base" and a.batch == 256:
+            # -- and only while that pass describes THIS library: the summary carries a fingerprint of the kernel sources it profiled
+            pmc = os.path.join(ROOT, "profiles", "r02_pmc_summary.json")
+            if os.path.exists(pmc) and a.config == "ctrl_vilbert_base" and a.batch == 256 and a.dtype == "bf16":
                 pm = json.load(open(pmc))
-                out["roofline"]["traffic"] = pm["hbm_bytes_per_launch"]
-                out["roofline"]["traffic_note"] = "HBM bytes per GEMM launch (avg of %d launches/step), FETCH_SIZE x2 + WRITE_SIZE from profiles/r01_pmc_summary.json" % pm["launches_per_step"]
+                if pm.get("source_fingerprint") == source_fingerprint():
+                    out["roofline"]["traffic"] = pm["hbm_bytes_per_launch"]
+                    out["roofline"]["traffic_note"] = ("HBM bytes per GEMM launch (avg of %d launches/step), FETCH_SIZE x2 + WRITE_SIZE from profiles/r02_pmc_summary.json "
+                                                       "(rocprofv3 --pmc passes over this command; kernel sources unchanged since)" % pm["launches_per_step"])
+                else:
+                    out["roofline"]["traffic_note"] = "profiles/r02_pmc_summary.json was collected on different kernel sources: traffic withheld (re-run tools/collect_profiles.sh)"
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.config, a.seq_len, a.regions)

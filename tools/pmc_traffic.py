@@ -22,7 +22,10 @@ with open(out_md, "w") as md:
 g = [d for k, d in rows.items() if "gemm" in k]
 n = sum(d["n"] for d in g) / steps
 fb, wb = sum(2.0 * d["f"] * 1024 for d in g) / steps, sum(d["w"] * 1024 for d in g) / steps
-json.dump({"kernel": "vk::gemm256k_kernel / vk::gemm_kernel family", "launches_per_step": n, "fetch_bytes_per_step": fb, "write_bytes_per_step": wb,
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+json.dump({"source_fingerprint": bench.source_fingerprint(), "kernel": "vk::gemm256k_kernel / gemm256p_kernel / gemm_kernel family", "launches_per_step": n, "fetch_bytes_per_step": fb, "write_bytes_per_step": wb,
            "hbm_bytes_per_launch": (fb + wb) / n,
            "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 1 --serial`; KB units x1024; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B)"},
           open(out_json, "w"), indent=1)

@@ -151,14 +151,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         }
         if (k0) { stage_store<TP>(kimg[0], rk0, tid, nthr); stage_store<TP>(vimg[0], rv0, tid, nthr); }
         if (k1) { stage_store<RP>(kimg[1], rk1, tid, nthr); stage_store<RP>(vimg[1], rv1, tid, nthr); }
+        if (tid == 0) *(int VK_LDS*)(uintptr_t)(lds0 + 2 * (TP + RP) * 128) = 0;
     }
     __syncthreads();
 
     const int nqt0 = (a.gate[0][0] || a.gate[0][1]) ? (a.L[0] + 15) / 16 : 0;
     const int nqt1 = (a.gate[1][0] || a.gate[1][1]) ? (a.L[1] + 15) / 16 : 0;
-    for (int task = wave; task < nqt0 + nqt1; task += nwaves) {
-        const int mq = task < nqt0 ? 0 : 1;
-        const int qt = mq ? task - nqt0 : task;
+    // Tasks (16-query tiles) are claimed from a counter in LDS, vision tiles (more keys per tile) first: 5 tiles on 4 waves in fixed
+    // round-robin order left one wave with text + vision tile while the others idled.
+    int VK_LDS* const next_task = (int VK_LDS*)(uintptr_t)(lds0 + 2 * (TP + RP) * 128);
+    (void)nwaves;
+    for (;;) {
+        int task = 0;
+        if (lane == 0) task = __hip_atomic_fetch_add(next_task, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        task = __builtin_amdgcn_readfirstlane(task);
+        if (task >= nqt0 + nqt1) break;
+        const int mq = task < nqt1 ? 1 : 0;
+        const int qt = mq ? task : task - nqt1;
         const int Lq = a.L[mq];
         const int qi = qt * 16 + lq;
         const bool qvalid = qi < Lq;
@@ -300,17 +309,27 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             stage_store<RP>(qimg[1], rq1, tid, nthr); stage_store<RP>(gimg[1], rg1, tid, nthr);
             delta_rows<RP>(rg1, ro1, del_s + rbase[1], lse_s + rbase[1], a.lse[1] + ((size_t)b * a.nh + h) * a.L[1], a.L[1], tid, nthr);
         }
+        if (tid == 0) *(int VK_LDS*)(uintptr_t)(lds0 + 4 * ROWS * 128 + 2 * ROWS * 4) = 0;
     }
     __syncthreads();
 
     const int nkt0 = kact[0] ? (a.L[0] + 15) / 16 : 0, nkt1 = kact[1] ? (a.L[1] + 15) / 16 : 0;
     const int nqt0 = qact[0] ? (a.L[0] + 15) / 16 : 0, nqt1 = qact[1] ? (a.L[1] + 15) / 16 : 0;
     const int nktasks = nkt0 + nkt1, ntasks = nktasks + nqt0 + nqt1;
-    for (int task = wave; task < ntasks; task += nwaves) {
+    // Tasks are claimed from a counter in LDS in the order key tiles (two accumulators: the heavier role) before query tiles, vision
+    // before text: 10 tasks of unequal weight on 4 waves in fixed round-robin order left one wave with 4.5 units of work against 3.5 on
+    // average.
+    int VK_LDS* const next_task = (int VK_LDS*)(uintptr_t)(lds0 + 4 * ROWS * 128 + 2 * ROWS * 4);
+    (void)nwaves;
+    for (;;) {
+        int task = 0;
+        if (lane == 0) task = __hip_atomic_fetch_add(next_task, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        task = __builtin_amdgcn_readfirstlane(task);
+        if (task >= ntasks) break;
         if (task < nktasks) {
             // ---------------- key-tile role: dK, dV of 16 keys of modality mk ----------------
-            const int mk = task < nkt0 ? 0 : 1;
-            const int kt = mk ? task - nkt0 : task;
+            const int mk = task < nkt1 ? 1 : 0;
+            const int kt = mk ? task : task - nkt1;
             const int Lk = a.L[mk];
             const int key = kt * 16 + lq;
             const bool kvalid = key < Lk;
@@ -381,8 +400,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         } else {
             // ---------------- query-tile role: dQ of 16 queries of modality mq ----------------
             const int t2 = task - nktasks;
-            const int mq = t2 < nqt0 ? 0 : 1;
-            const int qt = mq ? t2 - nqt0 : t2;
+            const int mq = t2 < nqt1 ? 1 : 0;
+            const int qt = mq ? t2 : t2 - nqt1;
             const int Lq = a.L[mq];
             const int qi = qt * 16 + lq;
             const bool qvalid = qi < Lq;
@@ -472,7 +491,7 @@ static int g_attn_fwd_waves = 4;    // waves per workgroup (query tiles are loop
 static int g_attn_fwd_occ = 4;      // tuning hook: waves per SIMD the register allocation targets (5 spills 16-74 dwords: slower)
 template <int TP, int RP>
 static int launch_fwd(const AttnK& k, int nq_tiles, hipStream_t s) {
-    const int lds = 2 * (TP + RP) * 128;
+    const int lds = 2 * (TP + RP) * 128 + 16;          // + the task counter
     int waves = nq_tiles < 4 ? 4 : (nq_tiles > 8 ? 8 : nq_tiles);      // staging is sized for >= 256 threads
     if (g_attn_fwd_waves >= 4 && g_attn_fwd_waves < waves && 4 * lds <= 160 * 1024) waves = g_attn_fwd_waves;     // only where four workgroups fit the CU's LDS
     if (g_attn_fwd_occ == 5) hipLaunchKernelGGL((attn_fwd_kernel<TP, RP, 5>), dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
@@ -484,7 +503,7 @@ static int g_attn_bwd_occ = 3;      // waves per SIMD the register allocation ta
 
 template <int TP, int RP>
 static int launch_bwd(const AttnK& k, int ntasks, hipStream_t s) {
-    const int lds = 4 * (TP + RP) * 128 + 2 * (TP + RP) * 4;
+    const int lds = 4 * (TP + RP) * 128 + 2 * (TP + RP) * 4 + 16;          // + the task counter
     if (g_attn_bwd_occ == 3 && 3 * lds <= 160 * 1024) {       // three workgroups only fit with the small images
         auto kern = attn_bwd_kernel<TP, RP, 3>;
         static bool once = false;
