@@ -12,3 +12,5 @@ run uniter_b256 --config ctrl_uniter_base
 run visualbert_b256 --config ctrl_visualbert_base
 run vlbert_b256 --config ctrl_vl-bert_base
 run vlbert_r100_b256 --config ctrl_vl-bert_base --regions 100
+run vlbert_r100_b256_fp8 --config ctrl_vl-bert_base --regions 100 --dtype fp8
+run uniter_b512_fp8 --config ctrl_uniter_base --batch 512 --dtype fp8
