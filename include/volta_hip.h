@@ -416,8 +416,11 @@ int vk_run_ops(const vk_op* ops, int n, vk_stream_t s);
 /* Same, bracketing each op with HIP events on `s`; synchronises `s` and adds elapsed ms per op to ms[0..n).
    Side-stream blocks run inline on `s` here, so that every op's duration is attributed to it. */
 int vk_run_ops_timed(const vk_op* ops, int n, vk_stream_t s, float* ms);
-/* Make `s` wait for everything issued so far on the side stream (what VK_OP_JOIN does). */
+/* Make `s` wait for everything issued so far on ITS side stream (what VK_OP_JOIN does).  Every caller stream has a side stream and
+   events of its own (created on first use), so command lists replayed on different streams / from different threads share nothing. */
 int vk_side_join(vk_stream_t s);
+/* Make `waiter` (e.g. a communication stream) wait for the side stream that belongs to `owner` (the stream the lists run on). */
+int vk_side_join_from(vk_stream_t owner, vk_stream_t waiter);
 /* 0: run side-stream blocks inline on the caller's stream (serial schedule); 1 (default): concurrently. */
 void vk_side_enable(int on);
 

@@ -201,6 +201,7 @@ _sig("vk_ln_fwd_pair", C.c_int, C.POINTER(LnArgs), C.POINTER(LnArgs), c_p)
 _sig("vk_ln_bwd_pair", C.c_int, C.POINTER(LnBwdArgs), C.POINTER(LnBwdArgs), c_p)
 _sig("vk_concap_batch", C.c_int, C.POINTER(ConcapArgs), c_p)
 _sig("vk_side_join", C.c_int, c_p)
+_sig("vk_side_join_from", C.c_int, c_p, c_p)
 _sig("vk_side_enable", None, C.c_int)
 
 EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_cast_f32_bf16", "vk_gemm_grouped", "vk_gemm_grouped_ex", "vk_gemm_fp8_grouped", "vk_quant_rows_fp8", "vk_cast_bf16_fp8",
@@ -210,7 +211,7 @@ EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_c
            "vk_relu_bwd_bf16", "vk_copy_async", "vk_select_rows", "vk_gather_rows", "vk_scatter_rows_add", "vk_xent_fwd",
            "vk_xent_bwd", "vk_kl_fwd", "vk_kl_bwd", "vk_loss_finalize", "vk_pool_mul_fwd", "vk_pool_mul_bwd",
            "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_grad_norm_clip_masked", "vk_adamw_step",
-           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_side_tail", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_enable", "vk_concap_batch"]
+           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_side_tail", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_join_from", "vk_side_enable", "vk_concap_batch"]
 
 
 def check(rc):

@@ -462,6 +462,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     }
 }
 
+// launch-shape constants (measured); mutable only in VK_STUDY builds (tools/bench_small.py)
+#ifdef VK_STUDY
+#define VK_ATTN_TUNABLE static int
+#else
+#define VK_ATTN_TUNABLE static constexpr int
+#endif
+
 static int fill(AttnK& k, const vk_attn_args* a, const vk_attn_bwd_args* bw) {
     for (int m = 0; m < 2; ++m) {
         k.q[m] = (const uint16_t*)a->q[m]; k.k[m] = (const uint16_t*)a->k[m]; k.v[m] = (const uint16_t*)a->v[m];
@@ -487,8 +494,8 @@ static int fill(AttnK& k, const vk_attn_args* a, const vk_attn_bwd_args* bw) {
     return 0;
 }
 
-static int g_attn_fwd_waves = 4;    // waves per workgroup (query tiles are looped): 4 workgroups of 4 waves fill the CU's 16 wave slots, one wave per tile (5) leaves it at 3 workgroups (measured -18 %)
-static int g_attn_fwd_occ = 4;      // tuning hook: waves per SIMD the register allocation targets (5 spills 16-74 dwords: slower)
+VK_ATTN_TUNABLE g_attn_fwd_waves = 4;    // waves per workgroup (query tiles are looped): 4 workgroups of 4 waves fill the CU's 16 wave slots, one wave per tile (5) leaves it at 3 workgroups (measured -18 %)
+VK_ATTN_TUNABLE g_attn_fwd_occ = 4;      // tuning hook: waves per SIMD the register allocation targets (5 spills 16-74 dwords: slower)
 template <int TP, int RP>
 static int launch_fwd(const AttnK& k, int nq_tiles, hipStream_t s) {
     const int lds = 2 * (TP + RP) * 128 + 16;          // + the task counter
@@ -498,22 +505,20 @@ static int launch_fwd(const AttnK& k, int nq_tiles, hipStream_t s) {
     else hipLaunchKernelGGL((attn_fwd_kernel<TP, RP, 4>), dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
     return check_launch("vk_gated_attn_fwd");
 }
-static int g_attn_bwd_waves = 4;    // waves per workgroup (tasks are looped): 4 lets two workgroups share a CU (measured -15 %)
-static int g_attn_bwd_occ = 3;      // waves per SIMD the register allocation targets: 3 (<= 168 VGPRs, a few spilled dwords) lets three 4-wave workgroups share a CU (-3..-9 % against 2)
+VK_ATTN_TUNABLE g_attn_bwd_waves = 4;    // waves per workgroup (tasks are looped): 4 lets two workgroups share a CU (measured -15 %)
+VK_ATTN_TUNABLE g_attn_bwd_occ = 3;      // waves per SIMD the register allocation targets: 3 (<= 168 VGPRs, a few spilled dwords) lets three 4-wave workgroups share a CU (-3..-9 % against 2)
 
 template <int TP, int RP>
 static int launch_bwd(const AttnK& k, int ntasks, hipStream_t s) {
     const int lds = 4 * (TP + RP) * 128 + 2 * (TP + RP) * 4 + 16;          // + the task counter
     if (g_attn_bwd_occ == 3 && 3 * lds <= 160 * 1024) {       // three workgroups only fit with the small images
         auto kern = attn_bwd_kernel<TP, RP, 3>;
-        static bool once = false;
-        if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
+        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); (void)attr;      // once per process, thread-safe
         int waves = g_attn_bwd_waves < 4 ? 4 : (ntasks > g_attn_bwd_waves ? g_attn_bwd_waves : (ntasks < 4 ? 4 : ntasks));
         hipLaunchKernelGGL(kern, dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
     } else {
         auto kern = attn_bwd_kernel<TP, RP, 2>;
-        static bool once = false;
-        if (!once) { (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); once = true; }
+        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); (void)attr;      // once per process, thread-safe
         int waves = g_attn_bwd_waves < 4 ? 4 : (ntasks > g_attn_bwd_waves ? g_attn_bwd_waves : (ntasks < 4 ? 4 : ntasks));      // staging is sized for >= 256 threads
         hipLaunchKernelGGL(kern, dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
     }
@@ -554,7 +559,9 @@ extern "C" int vk_gated_attn_bwd(const vk_attn_args* a, const vk_attn_bwd_args* 
     if (!bigT && bigR) return launch_bwd<32, 128>(k, nt, s);
     return launch_bwd<64, 128>(k, nt, s);
 }
+#ifdef VK_STUDY
 extern "C" void vk_attn_set_bwd_occupancy(int v) { vk::g_attn_bwd_occ = v; }
 extern "C" void vk_attn_set_bwd_waves(int v) { vk::g_attn_bwd_waves = v; }
 extern "C" void vk_attn_set_fwd_waves(int v) { vk::g_attn_fwd_waves = v; }
 extern "C" void vk_attn_set_fwd_occupancy(int v) { vk::g_attn_fwd_occ = v; }
+#endif

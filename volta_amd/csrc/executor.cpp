@@ -9,7 +9,11 @@
 
 static int run_one(const vk_op& o, int i, vk_stream_t s);
 
-// ---- side stream: one per process (one process drives one GPU), created on first use
+// ---- side streams: one (with its events) per CALLER stream, created on first use and kept for the life of the process.  Two host
+// threads replaying command lists on two streams therefore never share a side stream or an event (re-entrant across streams); the
+// map itself is guarded by a mutex.  vk_side_enable() is the only process-wide switch (profiling: run side blocks inline).
+#include <mutex>
+#include <unordered_map>
 namespace {
 constexpr int N_SIDE_EVENTS = 16;
 struct Side {
@@ -19,53 +23,70 @@ struct Side {
     bool recorded[N_SIDE_EVENTS] = {};
     bool ok = false;
 };
-Side g_side;
+std::mutex g_side_mutex;
+std::unordered_map<void*, Side*> g_sides;
 int g_side_enabled = 1;
 
-int side_init() {
-    if (g_side.ok) return 0;
-    if (hipStreamCreateWithFlags(&g_side.stream, hipStreamNonBlocking) != hipSuccess) return vk::set_error("side stream: hipStreamCreate failed");
-    if (hipEventCreateWithFlags(&g_side.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g_side.join, hipEventDisableTiming) != hipSuccess)
-        return vk::set_error("side stream: hipEventCreate failed");
+Side* side_lookup(vk_stream_t caller) {
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    auto it = g_sides.find((void*)caller);
+    return it == g_sides.end() ? nullptr : it->second;
+}
+
+Side* side_for(vk_stream_t caller) {
+    std::lock_guard<std::mutex> lock(g_side_mutex);
+    Side*& sp = g_sides[(void*)caller];
+    if (sp && sp->ok) return sp;
+    if (!sp) sp = new Side();
+    Side& g = *sp;
+    if (hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) != hipSuccess) { vk::set_error("side stream: hipStreamCreate failed"); return nullptr; }
+    if (hipEventCreateWithFlags(&g.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g.join, hipEventDisableTiming) != hipSuccess) {
+        vk::set_error("side stream: hipEventCreate failed");
+        return nullptr;
+    }
     for (int i = 0; i < N_SIDE_EVENTS; ++i)
-        if (hipEventCreateWithFlags(&g_side.done[i], hipEventDisableTiming) != hipSuccess) return vk::set_error("side stream: hipEventCreate failed");
-    g_side.ok = true;
-    return 0;
+        if (hipEventCreateWithFlags(&g.done[i], hipEventDisableTiming) != hipSuccess) { vk::set_error("side stream: hipEventCreate failed"); return nullptr; }
+    g.ok = true;
+    return sp;
 }
 }  // namespace
 
 extern "C" void vk_side_enable(int on) { g_side_enabled = on; }
 
-extern "C" int vk_side_join(vk_stream_t s) {
-    if (!g_side.ok) return 0;           // nothing was ever issued on the side stream
-    if (hipEventRecord(g_side.join, g_side.stream) != hipSuccess) return vk::set_error("vk_side_join: hipEventRecord failed");
-    if (hipStreamWaitEvent((hipStream_t)s, g_side.join, 0) != hipSuccess) return vk::set_error("vk_side_join: hipStreamWaitEvent failed");
+extern "C" int vk_side_join_from(vk_stream_t owner, vk_stream_t waiter) {
+    Side* g = side_lookup(owner);
+    if (!g || !g->ok) return 0;           // nothing was ever issued on this stream's side stream
+    if (hipEventRecord(g->join, g->stream) != hipSuccess) return vk::set_error("vk_side_join: hipEventRecord failed");
+    if (hipStreamWaitEvent((hipStream_t)waiter, g->join, 0) != hipSuccess) return vk::set_error("vk_side_join: hipStreamWaitEvent failed");
     return 0;
 }
 
+extern "C" int vk_side_join(vk_stream_t s) { return vk_side_join_from(s, s); }
+
 extern "C" int vk_run_ops(const vk_op* ops, int n, vk_stream_t s) {
     vk_stream_t cur = s;
+    Side* g = nullptr;
     for (int i = 0; i < n; ++i) {
         const vk_op& o = ops[i];
         if (o.kind >= VK_OP_SIDE_BEGIN && o.kind <= VK_OP_JOIN) {
             if (!g_side_enabled) continue;
-            if (side_init() != 0) return -1;
+            if (!g && !(g = side_for(s))) return -1;
             hipError_t e = hipSuccess;
             switch (o.kind) {
                 case VK_OP_SIDE_BEGIN:
-                    e = hipEventRecord(g_side.fork, (hipStream_t)s);
-                    if (e == hipSuccess) e = hipStreamWaitEvent(g_side.stream, g_side.fork, 0);
-                    cur = (vk_stream_t)g_side.stream;
+                    e = hipEventRecord(g->fork, (hipStream_t)s);
+                    if (e == hipSuccess) e = hipStreamWaitEvent(g->stream, g->fork, 0);
+                    cur = (vk_stream_t)g->stream;
                     break;
                 case VK_OP_SIDE_END:
                     if (o.i0 < 0 || o.i0 >= N_SIDE_EVENTS) return vk::set_error("vk_run_ops: side event %d out of range", o.i0);
-                    e = hipEventRecord(g_side.done[o.i0], g_side.stream);
-                    g_side.recorded[o.i0] = true;
+                    e = hipEventRecord(g->done[o.i0], g->stream);
+                    g->recorded[o.i0] = true;
                     cur = s;
                     break;
                 case VK_OP_WAIT_SIDE:
                     if (o.i0 < 0 || o.i0 >= N_SIDE_EVENTS) return vk::set_error("vk_run_ops: side event %d out of range", o.i0);
-                    if (g_side.recorded[o.i0]) e = hipStreamWaitEvent((hipStream_t)s, g_side.done[o.i0], 0);
+                    if (g->recorded[o.i0]) e = hipStreamWaitEvent((hipStream_t)s, g->done[o.i0], 0);
                     break;
                 default:
                     if (vk_side_join(s) != 0) return -1;
@@ -83,7 +104,7 @@ extern "C" int vk_run_ops(const vk_op* ops, int n, vk_stream_t s) {
 // Profiling variant: brackets every op with HIP events on the launch stream, synchronises once at the end and
 // ADDS each op's elapsed milliseconds to ms[i].  Used by bench.py for the live per-kernel-class timings.
 extern "C" int vk_run_ops_timed(const vk_op* ops, int n, vk_stream_t s, float* ms) {
-    static std::vector<hipEvent_t> ev;
+    static thread_local std::vector<hipEvent_t> ev;      // profiling helper: events are reused by the calling thread
     while ((int)ev.size() < n + 1) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return vk::set_error("vk_run_ops_timed: hipEventCreate failed");

@@ -197,9 +197,13 @@ class Plan:
             else:
                 check(L.lib.vk_run_ops(base, end - start, L.stream_ptr()))
 
-    def join_side(self):
-        """Make the current stream wait for the side-stream work (weight gradients) issued so far."""
-        check(L.lib.vk_side_join(L.stream_ptr()))
+    def join_side(self, owner=None):
+        """Make the current stream wait for the side-stream work (weight gradients) issued so far by lists run on stream `owner`
+        (a raw stream handle; default: the current stream itself)."""
+        if owner is None:
+            check(L.lib.vk_side_join(L.stream_ptr()))
+        else:
+            check(L.lib.vk_side_join_from(C.c_void_p(owner), L.stream_ptr()))
 
     def enable_timing(self, on=True):
         """Per-op HIP-event timing (synchronises the stream on every run; profiling passes only)."""

@@ -176,11 +176,12 @@ class DistributedDataParallel(nn.Module):
     def run_backward(self, eng):
         start = 0
         self.reducer.bytes_on_wire = 0
+        owner = torch.cuda.current_stream().cuda_stream if self.reducer.cuda else None      # the executor keeps one side stream per caller stream
         for end, ranges in self._plan(eng):
             eng.bwd.run(start, end)
             # the bucket's weight gradients were computed on the executor's side stream: the communication stream waits
             # for them, the compute stream carries on with the backward
-            self.reducer.reduce(ranges, join=eng.bwd.join_side)
+            self.reducer.reduce(ranges, join=lambda: eng.bwd.join_side(owner))
             start = end
         eng.bwd.run(start, len(eng.bwd.ops))
         self.reducer.finish()
