@@ -48,11 +48,11 @@ def parse():
 def gemm_flops(eng, plan):
     """Algorithmic FLOPs (2 M N K) of every GEMM op in a plan; device-side row counts are read back."""
     from volta_amd import _lib as L
-    out = {}
+    out, bytes_out = {}, {}
     for i, (kind, layout, epi, nprob, arr, _, _) in enumerate(plan.ops):
         if kind not in (L.OP_GEMM, L.OP_GEMM_FP8):
             continue
-        fl = 0.0
+        fl, by = 0.0, 0.0
         for j in range(nprob):
             q = arr[j].p if kind == L.OP_GEMM_FP8 else arr[j]
             M, K = q.M, q.K
@@ -63,7 +63,16 @@ def gemm_flops(eng, plan):
                 else:
                     M = min(M, n)
             fl += 2.0 * M * q.N * K
+            eo = 1 if kind == L.OP_GEMM_FP8 else 2                                     # operand bytes per element
+            ec = 4 if epi in (L.EPI_F32, L.EPI_F32_ACC) else 2                         # output bytes per element
+            by += (M * K + q.N * K) * eo + M * q.N * ec * (2 if epi == L.EPI_GELU else 1)     # every operand read once, every output written once
+            if epi in (L.EPI_MULR, L.EPI_ADDR):
+                by += M * q.N * 2                                                      # the multiplier / residual operand
+            if epi == L.EPI_F32_ACC:
+                by += M * q.N * 4
         out[i] = fl
+        bytes_out[i] = by
+    gemm_flops.compulsory_bytes = bytes_out
     return out
 
 

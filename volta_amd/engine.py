@@ -276,7 +276,9 @@ class StepEngine:
         return t
 
     def tmp(self, name, shape, dtype=torch.bfloat16):
-        """Backward temporaries are shared by all sub-layers."""
+        """Backward temporaries are shared by all sub-layers (launches on one stream are ordered).  Ops that are being built for a
+        side-stream block run NEXT to main-stream launches: they get temporaries of their own (`_aside`)."""
+        name += getattr(self, "_aside", "")
         if name not in self.bufs:
             self.bufs[name] = torch.empty(shape, dtype=dtype, device=self.dev)
         t = self.bufs[name]
@@ -366,10 +368,14 @@ class StepEngine:
             q.zero_()
         return q, self.tmp("fp8_xs%d" % m, (M,), torch.float32)
 
-    def ln_bwd_args(self, dy, z, mean, rstd, gname, bname, dz, dd, M, drop, post=0, out_scale=1.0, dyn=None, segs=None, accumulate=0, defer=False):
+    def ln_bwd_args(self, dy, z, mean, rstd, gname, bname, dz, dd, M, drop, post=0, out_scale=1.0, dyn=None, segs=None, accumulate=0, defer=False, own_partial=False):
         """`defer`: the dgamma / dbeta column reduction is left to an OP_LN_FINALIZE that the next _wgrad() places in its
-        side-stream block; the partial records then need a buffer of their own."""
-        if defer:
+        side-stream block; the partial records then need a buffer of their own.  `own_partial`: this launch runs inside a side-stream
+        block, next to main-stream LayerNorm backwards -- it cannot share their scratch records either."""
+        if (own_partial or getattr(self, "_aside", "")) and not defer:
+            self._n_ln_partial = getattr(self, "_n_ln_partial", 0) + 1
+            partial = self.buf("ln_partial_%d" % self._n_ln_partial, (L.lib.vk_ln_bwd_partial_rows(M) * 2 * self.H,), torch.float32)
+        elif defer:
             self._n_ln_partial = getattr(self, "_n_ln_partial", 0) + 1
             partial = self.buf("ln_partial_%d" % self._n_ln_partial, (L.lib.vk_ln_bwd_partial_rows(M) * 2 * self.H,), torch.float32)
             accumulate |= 2
@@ -414,7 +420,9 @@ class StepEngine:
         if kind in ("vilbert", "lxmert"):
             bwd_stages.append(self._emb_text("bert.embeddings."))
             i0 = len(f)
+            self._aside = "_aside" if emb_image_aside else ""           # its backward runs in a side-stream block: own temporaries and LayerNorm scratch
             img_bwd = (self._emb_image_vilbert if kind == "vilbert" else self._emb_image_lxmert)("bert.v_embeddings.")
+            self._aside = ""
             if emb_image_aside:
                 f.insert(i0, (L.OP_SIDE_BEGIN, 0, 0, 0, None, None, None))
                 f.append((L.OP_SIDE_END, 15, 0, 0, None, None, None))
@@ -470,7 +478,10 @@ class StepEngine:
     # forward order) that transforms x[m] reads d(loss)/d(its output) from buffer k%2 and writes the gradient of
     # its input to buffer (k-1)%2; the embeddings read buffer 0, the heads fill buffer (final k)%2.
     def _dx(self, m, parity):
-        return self.tmp("dx%d_%d" % (m, parity), (self.st[m].M, self.H))
+        aside, self._aside = getattr(self, "_aside", ""), ""          # the hidden-state gradients are shared by definition
+        t = self.tmp("dx%d_%d" % (m, parity), (self.st[m].M, self.H))
+        self._aside = aside
+        return t
 
     def _dx_step(self, m):
         self.level[m] += 1
@@ -1114,7 +1125,7 @@ class StepEngine:
         self.gemm(b, L.TN, L.EPI_F32, [self.prob(dlog_v, hn_v, self.G(wdec + "weight"), Cn, H, Mr, Cp, H, H, bias_grad=self.G(wdec + "bias"), dyn=n_v)])
         if cfg.image_head_ln:
             dhv = self.tmp("head_v_d2", (Mr, H))
-            b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dhn_v, hv, im_mean, im_rstd, ci + "transform.LayerNorm.weight", ci + "transform.LayerNorm.bias", dhv, None, Mr, nodrop, dyn=n_v), None, None))
+            b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dhn_v, hv, im_mean, im_rstd, ci + "transform.LayerNorm.weight", ci + "transform.LayerNorm.bias", dhv, None, Mr, nodrop, dyn=n_v, own_partial=True), None, None))
         else:
             dhv = dhn_v
         du_v = self.tmp("head_v_d3", (Mr, H))
