@@ -331,7 +331,9 @@ def main():
                 step()
             torch.cuda.synchronize()
             fl = dict(("f%d" % i, v) for i, v in gemm_flops(eng, eng.fwd).items())
+            comp_bytes = sum(gemm_flops.compulsory_bytes.values())
             fl.update(("b%d" % i, v) for i, v in gemm_flops(eng, eng.bwd).items())
+            comp_bytes += sum(gemm_flops.compulsory_bytes.values())
             tms = dict(("f%d" % i, eng.fwd.timing[i] / nprof) for i in range(len(eng.fwd.ops)))
             tms.update(("b%d" % i, eng.bwd.timing[i] / nprof) for i in range(len(eng.bwd.ops)))
             gemm_ms = sum(tms[k] for k in fl)
@@ -365,6 +367,7 @@ def main():
                 "kernel": "vk::gemm256k_kernel / gemm256p_kernel / gemm_kernel (bf16 MFMA 16x16x32 GEMM family, all layouts and epilogues)"
                           + (" + vk::gemm_fp8_kernel (e4m3 MFMA 16x16x128, forward projections); priced against the bf16 peak" if a.dtype == "fp8" else ""),
                 "launches_per_step": len(fl), "algorithmic_gflop_per_launch": gemm_fl / 1e9 / len(fl), "avg_launch_us": gemm_ms * 1e3 / len(fl),
+                "compulsory_mbytes_per_launch": comp_bytes / 1e6 / len(fl),     # every operand read once + every output written once
                 "ms_per_step": gemm_ms, "timing": "HIP events on the launch stream around every launch, %d profiled steps, serial schedule" % nprof,
                 "sustained_mfma_note": "a register-only MFMA loop sustains ~1.75-2.0 PFLOP/s on this part (tools/bench_gemm.py peak); `peak` is the datasheet 2.5",
                 "whole_step": {"achieved": whole["achieved"], "frac": whole["frac"], "scope": whole["scope"]}}

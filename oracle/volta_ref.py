@@ -383,9 +383,37 @@ def bert_model(sd, cfg, input_ids, image_feat, image_loc, token_type_ids=None, a
             t, v = gated_ffn(sd, cfg, n, t, v, drop)
         if taps is not None:
             taps["t%d" % n], taps["v%d" % n] = t, v
-    pooled_t = torch.relu(linear(t[:, 0], sd, "bert.t_pooler.dense"))
-    pooled_v = torch.relu(linear(v[:, 0], sd, "bert.v_pooler.dense"))
+    # poolers by fusion method (encoders.py:936-947,1005-1011): "none" has neither, "text" / "vl-bert_vqa" no vision pooler;
+    # VLBertTextPooler (:610-623) pools the token two places before the end of the caption (text_end = number of non-zero ids)
+    fm = cfg.fusion_method
+    if fm == "none":
+        pooled_t = None
+    elif fm == "vl-bert_vqa":
+        text_end = (input_ids != 0).sum(1)
+        idx = text_end - 2
+        if bool((idx < 0).any()):
+            raise ValueError("VLBertTextPooler: a caption with fewer than two tokens selects no row (the reference's batch would shrink)")
+        pooled_t = torch.relu(linear(t[torch.arange(t.shape[0]), idx], sd, "bert.t_pooler.dense"))
+    else:
+        pooled_t = torch.relu(linear(t[:, 0], sd, "bert.t_pooler.dense"))
+    pooled_v = None if fm in ("none", "text", "vl-bert_vqa") else torch.relu(linear(v[:, 0], sd, "bert.v_pooler.dense"))
     return t, v, pooled_t, pooled_v
+
+
+def fuse_pooled(cfg, pooled_t, pooled_v, drop=None, p=0.1):
+    """BertPreTrainingHeads.forward / BertForVLTasks.forward (encoders.py:766-778,1184-1195)."""
+    fm = cfg.fusion_method
+    if fm == "sum":
+        x = pooled_t + pooled_v
+    elif fm == "mul":
+        x = pooled_t * pooled_v
+    elif fm in ("text", "vl-bert_vqa"):
+        x = pooled_t
+    elif fm == "none":
+        return None
+    else:
+        raise ValueError("Invalid fusion method: %s" % fm)
+    return drop(x, p) if drop is not None else x
 
 
 def kl_1601(pred, weight, label, target):
@@ -396,16 +424,112 @@ def kl_1601(pred, weight, label, target):
     return weight * (kl * m[..., None].to(kl.dtype)).sum() / max(int(m.sum()), 1)
 
 
+# ---- the other visual targets (losses.py:25-126); `label` [B,R] marks masked regions with 1
+VIS_TARGET_WIDTH = {"0": 1601, "1": 2048, "2": 2048, "3": 1600, "4": 400, "5": 2048, "6": 1601}      # losses.py:129-137
+NCE_ACROSS, NCE_INSIDE = int(128 * 0.7), int(128 * 0.3)      # 89 + 38 negatives per masked region (losses.py:39,45-46)
+
+
+def mse_2048(pred, weight, label, feat):
+    """losses.py:25-33: squared error against the (input) region features, mean over the masked regions' elements."""
+    m = (label == 1)
+    return weight * (((pred - feat) ** 2) * m[..., None].to(pred.dtype)).sum() / max(int(m.sum()) * pred.shape[2], 1)
+
+
+def huber_2048(pred, weight, label, feat):
+    """losses.py:105-113 (SmoothL1, beta 1)."""
+    m = (label == 1)
+    d = (pred - feat).abs()
+    l = torch.where(d < 1.0, 0.5 * d * d, d - 0.5)
+    return weight * (l * m[..., None].to(pred.dtype)).sum() / max(int(m.sum()) * pred.shape[2], 1)
+
+
+def xent_hard(pred, weight, label, target, conf=None):
+    """xent_1600 / xent_400 (losses.py:83-102: per-region cross entropy x detector confidence) and xent_1601 (:116-124, no confidence),
+    summed over the masked regions / max(#masked, 1)."""
+    l = F.cross_entropy(pred.reshape(-1, pred.shape[-1]), target.reshape(-1), reduction="none")
+    if conf is not None:
+        l = l * conf.reshape(-1)
+    m = (label.reshape(-1) == 1)
+    return weight * (l * m.to(l.dtype)).sum() / max(int(m.sum()), 1)
+
+
+def nce_negative_index(draws, B, R):
+    """losses.py:47-69 from the raw draws: draws["row_across"] in [0, B-1), ["col_across"] in [0, R) ([B,R,89]), ["col_inside"] in
+    [0, R-1) ([B,R,38]); the fix-ups steer a negative away from the sample's own image (across) / own region (inside).
+    -> flat indices [B, R, 127] into the [B*R, F] feature matrix."""
+    row = draws["row_across"].clone()
+    for i in range(B - 1):
+        row[i][row[i] == i] = B - 1
+    across = row * R + draws["col_across"]
+    col = draws["col_inside"].clone()
+    for i in range(R - 1):
+        c = col[:, i, :]
+        c[c == i] = R - 1
+    inside = torch.arange(B)[:, None, None] * R + col
+    return torch.cat([across, inside], 2)
+
+
+def nce_draws(seed, site, B, R):
+    """The product's negatives: word k of region (b, r) = Philox-4x32-10 word (k & 3) at counter (k >> 2, b * R + r, site, 0), reduced
+    modulo the range (torch's random_(0, n) is the same reduction of a 32/64-bit word)."""
+    n = NCE_ACROSS * 2 + NCE_INSIDE
+    c = np.arange((n + 3) // 4, dtype=np.uint32)
+    rows = np.arange(B * R, dtype=np.uint32)
+    w = philox_raw(np.broadcast_to(c[None, :], (B * R, len(c))).copy(), np.broadcast_to(rows[:, None], (B * R, len(c))).copy(),
+                   np.full((B * R, len(c)), site, np.uint32), np.zeros((B * R, len(c)), np.uint32),
+                   np.uint32(seed & 0xFFFFFFFF), np.uint32((seed >> 32) & 0xFFFFFFFF))
+    words = w.reshape(B * R, -1)[:, :n].astype(np.int64).reshape(B, R, n)
+    words = torch.from_numpy(words)
+    return dict(row_across=words[..., :NCE_ACROSS] % max(B - 1, 1), col_across=words[..., NCE_ACROSS:2 * NCE_ACROSS] % R,
+                col_inside=words[..., 2 * NCE_ACROSS:] % max(R - 1, 1))
+
+
+def nce_2048(pred, weight, label, feat, neg_index):
+    """losses.py:36-80: cross entropy (target 0) of <sample_j, prediction> over [own feature, 127 negatives], mean over the masked regions."""
+    m = (label == 1)
+    predict = pred[m]
+    flat = feat.reshape(-1, feat.shape[-1])
+    sample = torch.cat([feat[m].unsqueeze(1), flat[neg_index[m]]], 1)
+    score = torch.bmm(sample, predict.unsqueeze(2)).squeeze(2)
+    return weight * F.cross_entropy(score, torch.zeros(score.shape[0], dtype=torch.long))
+
+
+def visual_losses(cfg, scores_v, image_label, image_cls=None, image_feat=None, obj_labels=None, obj_confs=None, attr_labels=None,
+                  attr_confs=None, nce_index=None):
+    """encoders.py:1079-1087: sum of the configured targets' losses; a target whose inputs are missing contributes 0."""
+    total = torch.zeros(())
+    for ix, w in cfg.visual_target_weights.items():
+        sv = scores_v[ix]
+        sv = sv[:, :-1] if cfg.add_global_imgfeat == "last" else sv[:, int(cfg.add_global_imgfeat is not None):]
+        if not w > 0:
+            continue
+        if ix == "0" and image_cls is not None:
+            total = total + kl_1601(sv, w, image_label, image_cls)
+        elif ix == "1" and image_feat is not None:
+            total = total + mse_2048(sv, w, image_label, image_feat)
+        elif ix == "2" and image_feat is not None:
+            total = total + nce_2048(sv, w, image_label, image_feat, nce_index)
+        elif ix == "3" and obj_labels is not None and obj_confs is not None:
+            total = total + xent_hard(sv, w, image_label, obj_labels, obj_confs)
+        elif ix == "4" and attr_labels is not None and attr_confs is not None:
+            total = total + xent_hard(sv, w, image_label, attr_labels, attr_confs)
+        elif ix == "5" and image_feat is not None:
+            total = total + huber_2048(sv, w, image_label, image_feat)
+        elif ix == "6" and obj_labels is not None:
+            total = total + xent_hard(sv, w, image_label, obj_labels)
+    return total
+
+
 def pretrain_forward(sd, cfg, input_ids, image_feat, image_loc, token_type_ids=None, attention_mask=None,
                      image_attention_mask=None, masked_lm_labels=None, image_label=None, image_cls=None,
-                     next_sentence_label=None, train=False, philox_seed=None, taps=None):
+                     next_sentence_label=None, train=False, philox_seed=None, taps=None, obj_labels=None, obj_confs=None,
+                     attr_labels=None, attr_confs=None, nce_index=None):
     """-> (masked_lm_loss[1], img_loss[1], next_sentence_loss[1]) as the reference's
-    BertForVLPreTraining.forward (encoders.py:1044-1112); only visual target "0" (kl_1601)."""
-    assert cfg.fusion_method == "mul" and set(k for k, w in cfg.visual_target_weights.items() if w > 0) == {"0"}
+    BertForVLPreTraining.forward (encoders.py:1044-1112), every fusion method and visual target."""
     drop = Dropper(train, philox_seed)
     t, v, pt, pv = bert_model(sd, cfg, input_ids, image_feat, image_loc, token_type_ids, attention_mask,
                               image_attention_mask, drop, taps)
-    pooled = drop(pt * pv, 0.1)
+    pooled = fuse_pooled(cfg, pt, pv, drop, 0.1)
     c = "cls.predictions."
     h = layer_norm(gelu(linear(t, sd, c + "transform.dense")), sd[c + "transform.LayerNorm.weight"], sd[c + "transform.LayerNorm.bias"])
     scores_t = F.linear(h, sd["bert.embeddings.word_embeddings.weight"]) + sd[c + "bias"]
@@ -413,19 +537,19 @@ def pretrain_forward(sd, cfg, input_ids, image_feat, image_loc, token_type_ids=N
     hv = gelu(linear(v, sd, ci + "transform.dense"))
     if cfg.image_head_ln:
         hv = layer_norm(hv, sd[ci + "transform.LayerNorm.weight"], sd[ci + "transform.LayerNorm.bias"])
-    scores_v = linear(hv, sd, ci + "decoder_dict.0")
-    itm = linear(pooled, sd, "cls.bi_seq_relationship")
+    scores_v = {ix: linear(hv, sd, ci + "decoder_dict." + ix) for ix in cfg.visual_target_weights}
+    # the ITM head exists unless the fusion method is "none" / "vl-bert_vqa" (encoders.py:744-747)
+    itm = linear(pooled, sd, "cls.bi_seq_relationship") if cfg.fusion_method not in ("none", "vl-bert_vqa") else None
     if taps is not None:
-        taps.update(seq_t=t, seq_v=v, pooled_t=pt, pooled_v=pv, scores_t=scores_t, scores_v=scores_v, itm=itm)
-    if cfg.add_global_imgfeat == "last":
-        sv = scores_v[:, :-1]
-    else:
-        sv = scores_v[:, int(cfg.add_global_imgfeat is not None):]
-    img_loss = kl_1601(sv, cfg.visual_target_weights["0"], image_label, image_cls)
+        taps.update(seq_t=t, seq_v=v, pooled_t=pt, pooled_v=pv, scores_t=scores_t, scores_v=scores_v.get("0"), scores_v_dict=scores_v, itm=itm)
+    img_loss = visual_losses(cfg, scores_v, image_label, image_cls, image_feat, obj_labels, obj_confs, attr_labels, attr_confs, nce_index)
     if not float(img_loss.detach()) > 0:                       # encoders.py:1089-1093
         img_loss = torch.zeros(())
     lm_loss = F.cross_entropy(scores_t.reshape(-1, scores_t.shape[-1]), masked_lm_labels.reshape(-1), ignore_index=-1)
-    nsp_loss = F.cross_entropy(itm.view(-1, 2), next_sentence_label.view(-1))
+    if itm is not None and next_sentence_label is not None:
+        nsp_loss = F.cross_entropy(itm.view(-1, 2), next_sentence_label.view(-1))
+    else:
+        nsp_loss = torch.zeros(())                             # encoders.py:1101-1107
     return lm_loss.reshape(1), img_loss.reshape(1), nsp_loss.reshape(1)
 
 
@@ -574,16 +698,21 @@ def param_shapes(cfg):
             if has_v and not shared:
                 lin(p + "output.v_dense", Hv, Iv)
                 ln(p + "output.v_LayerNorm", Hv)
-    lin("bert.t_pooler.dense", cfg.pooler_size, H)
-    lin("bert.v_pooler.dense", cfg.v_pooler_size, Hv)
+    fm = cfg.fusion_method
+    if fm != "none":
+        lin("bert.t_pooler.dense", cfg.pooler_size, H)
+    if fm not in ("none", "text", "vl-bert_vqa"):
+        lin("bert.v_pooler.dense", cfg.v_pooler_size, Hv)
     s["cls.predictions.bias"] = (V,)
     lin("cls.predictions.transform.dense", H, H)
     ln("cls.predictions.transform.LayerNorm", H)
-    lin("cls.bi_seq_relationship", 2, cfg.pooler_size)
+    if fm not in ("none", "vl-bert_vqa"):
+        lin("cls.bi_seq_relationship", 2, cfg.pooler_size)
     lin("cls.imagePredictions.transform.dense", Hv, Hv)
     if cfg.image_head_ln:
         ln("cls.imagePredictions.transform.LayerNorm", Hv)
-    lin("cls.imagePredictions.decoder_dict.0", 1601, Hv)
+    for ix, w in cfg.visual_target_weights.items():          # encoders.py:718-723: one decoder per target, in the config's order
+        lin("cls.imagePredictions.decoder_dict." + ix, VIS_TARGET_WIDTH[ix], Hv)
     return s
 
 
@@ -683,13 +812,20 @@ def synthetic_batch(cfg, B, T=20, R=36, seed=1234, device="cpu", pad=False):
     batch = dict(input_ids=ids, input_mask=input_mask, segment_ids=torch.zeros(B, T, dtype=torch.long),
                  lm_label_ids=lm, is_match=is_match, image_feat=feat.contiguous(), image_loc=loc.contiguous(),
                  image_cls=cls, image_label=image_label, image_mask=image_mask)
+    if set(cfg.visual_target_weights) - {"0"}:                 # detector outputs for the hard-label targets (drawn last: the
+        g2 = torch.Generator().manual_seed(seed + 77)          # tensors above do not depend on the configured targets)
+        batch.update(obj_labels=torch.randint(0, 1600, (B, R), generator=g2), obj_confs=torch.rand(B, R, generator=g2),
+                     attr_labels=torch.randint(0, 400, (B, R), generator=g2), attr_confs=torch.rand(B, R, generator=g2))
+    if cfg.num_locs != 5:
+        batch["image_loc"] = batch["image_loc"][..., :cfg.num_locs].contiguous()
     return {k: v.to(device) for k, v in batch.items()}
 
 
 def forward_from_batch(sd, cfg, b, **kw):
     return pretrain_forward(sd, cfg, b["input_ids"], b["image_feat"], b["image_loc"], b["segment_ids"],
                             b["input_mask"], b["image_mask"], b["lm_label_ids"], b["image_label"],
-                            b["image_cls"], b["is_match"], **kw)
+                            b["image_cls"], b["is_match"], obj_labels=b.get("obj_labels"), obj_confs=b.get("obj_confs"),
+                            attr_labels=b.get("attr_labels"), attr_confs=b.get("attr_confs"), **kw)
 
 
 def hf_style_bert_state_dict(cfg, n_layers, seed=0, with_prefix=True):
@@ -785,12 +921,7 @@ def tasks_forward(sd, cfg, task_cfg, task_id, input_ids, image_feat, image_loc, 
     """BertForVLTasks.forward in eval mode (volta/encoders.py:1159-1206): vil_prediction."""
     seq_t, seq_v, pooled_t, pooled_v = bert_model(sd, cfg, input_ids, image_feat, image_loc, token_type_ids, attention_mask,
                                                    image_attention_mask, taps=taps)
-    if cfg.fusion_method == "mul":
-        pooled = pooled_t * pooled_v
-    elif cfg.fusion_method == "sum":
-        pooled = pooled_t + pooled_v
-    else:
-        raise ValueError(cfg.fusion_method)
+    pooled = fuse_pooled(cfg, pooled_t, pooled_v)
     typ, pre = task_cfg[task_id]["type"], "clfs_dict.%s." % task_id
 
     def simple(x):
