@@ -148,6 +148,152 @@ def write_ctrl(BertConfig, Model):
         del model, sd
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# the other fusion methods, global-feature placements and visual targets (volta/losses.py:25-126)
+def variant_configs():
+    big = dict(TINY_BASE, v_feature_size=2048)           # the feature-regression targets predict 2048 values per region
+    enc = dict(tt_attn_sublayers=[0, 2, 6], tv_attn_sublayers=[4], vt_attn_sublayers=[4], vv_attn_sublayers=[6],
+               t_ff_sublayers=[1, 3, 5, 7], v_ff_sublayers=[5, 7])
+    single = dict(tt_attn_sublayers=[0, 2], tv_attn_sublayers=[0, 2], vt_attn_sublayers=[0, 2], vv_attn_sublayers=[0, 2],
+                  t_ff_sublayers=[1, 3], v_ff_sublayers=[1, 3], shared_sublayers=[0, 1, 2, 3], single_ln_sublayers=[0, 1, 2, 3])
+    c = {}
+    # lxmert.json's heads: text-only fusion, no global feature, 4 box coordinates, detector-label + regression targets
+    c["var_lxmert_text"] = dict(big, image_embeddings="lxmert", fusion_method="text", add_global_imgfeat=None, num_locs=4,
+                                visual_target_weights={"3": 6.667, "4": 6.667, "5": 6.667},
+                                tt_attn_sublayers=[0, 2, 5], vv_attn_sublayers=[0, 5], tv_attn_sublayers=[4], vt_attn_sublayers=[4],
+                                shared_sublayers=[4], t_ff_sublayers=[1, 3, 6], v_ff_sublayers=[1, 6])
+    # vl-bert_base.json's heads: no poolers, no ITM head, global feature LAST, hard labels over 1601 classes
+    c["var_vlbert_none"] = dict(TINY_BASE, image_embeddings="vl-bert", type_vocab_size=3, image_head_ln=False, v_coordinate_embeddings_dim=4,
+                                fusion_method="none", add_global_imgfeat="last", num_locs=4, visual_target_weights={"6": 1.0}, **single)
+    c["var_sum_mse_kl"] = dict(big, image_embeddings="vilbert", fusion_method="sum", add_global_imgfeat=None,
+                               visual_target_weights={"1": 2.0, "0": 0.5}, **enc)
+    c["var_vqa_nce"] = dict(big, image_embeddings="vilbert", fusion_method="vl-bert_vqa", add_global_imgfeat=None,
+                            visual_target_weights={"2": 1.5}, **enc)
+    return c
+
+
+VARIANT_GRAD_KEYS = GRAD_KEYS + ["cls.imagePredictions.decoder_dict.%s.weight" % ix for ix in "123456"] + \
+    ["cls.imagePredictions.transform.dense.weight", "bert.v_pooler.dense.weight", "bert.encoder.layer.0.attention_self.v_query.weight"]
+
+
+class _FedRandom:
+    """Replays explicit draws through Tensor.random_ (losses.py:50-51,59): the n-th call returns the n-th queued tensor.
+    nce_2048 as written cannot run on any torch >= 0.4: its index tensors and its class target come from `image_target.new(...)`,
+    i.e. they are FLOAT tensors, and `flat_image_target[neg_index_v]` (losses.py:75) raises "tensors used as indices must be long".
+    Inside this context `Tensor.new(*sizes)` returns int64 storage, which is what the code evidently intends; nothing else changes."""
+
+    def __init__(self, queue):
+        self.queue, self.orig, self.orig_new = list(queue), torch.Tensor.random_, torch.Tensor.new
+
+    def __enter__(self):
+        q, orig_new = self.queue, self.orig_new
+
+        def fake(t, *a, **k):
+            v = q.pop(0)
+            assert tuple(v.shape) == tuple(t.shape), (v.shape, t.shape)
+            return t.copy_(v.to(t.dtype))
+
+        def new_long(t, *sizes, **k):
+            if sizes and all(isinstance(x, int) for x in sizes) and not k:
+                return torch.zeros(*sizes, dtype=torch.long)
+            return orig_new(t, *sizes, **k)
+        torch.Tensor.random_ = fake
+        torch.Tensor.new = new_long
+        return self
+
+    def __exit__(self, *exc):
+        torch.Tensor.random_ = self.orig
+        torch.Tensor.new = self.orig_new
+        assert exc[0] is not None or not self.queue, "unused draws"
+
+
+def run_reference_variant(BertConfig, Model, cd, sd, batch, draws=None):
+    cfg = BertConfig.from_dict(cd)
+    model = Model(cfg)
+    model.load_state_dict(sd, strict=True)
+    model.eval()
+    b = {k: v.clone() for k, v in batch.items()}
+    args = (b["input_ids"], b["image_feat"], b["image_loc"], b["segment_ids"], b["input_mask"], b["image_mask"], b["lm_label_ids"],
+            b["image_label"], b["image_cls"], b.get("obj_labels"), b.get("obj_confs"), b.get("attr_labels"), b.get("attr_confs"), None, b["is_match"])
+    if draws is not None:
+        with _FedRandom([draws["row_across"], draws["col_across"], draws["col_inside"]]):
+            lm, img, nsp = model(*args)
+    else:
+        lm, img, nsp = model(*args)
+    seq_t, seq_v, pt, pv, _ = model.bert(b["input_ids"], batch["image_feat"].clone(), b["image_loc"], b["segment_ids"], b["input_mask"], b["image_mask"])
+    out = dict(loss_lm=lm.detach().numpy(), loss_img=img.detach().numpy(), loss_nsp=nsp.detach().numpy(),
+               seq_t=seq_t.detach().numpy(), seq_v=seq_v.detach().numpy())
+    if pt is not None:
+        out["pooled_t"] = pt.detach().numpy()
+    if pv is not None:
+        out["pooled_v"] = pv.detach().numpy()
+    (lm + img + nsp).sum().backward()
+    named = dict(model.named_parameters())
+    for k in VARIANT_GRAD_KEYS:
+        if k in named and named[k].grad is not None:
+            out["grad::" + k] = named[k].grad.numpy().copy()
+    out["grad_none"] = np.array(sorted(k for k, p in named.items() if p.grad is None))      # parameters the step must leave alone
+    total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None))
+    out["grad_norm"] = np.array([float(total)])
+    return out, model
+
+
+def write_variants(BertConfig, Model):
+    import json
+    for name, cd in variant_configs().items():
+        cfg = R.RefConfig(cd)
+        sd = R.make_weights(cfg, seed=7)
+        B, T, Rn = 3, 6, 7
+        seed = 11
+        while True:                                    # a batch with a few masked regions left after the objective-1 relabel
+            batch = R.synthetic_batch(cfg, B=B, T=T, R=Rn, seed=seed, pad=True)
+            if int((batch["image_label"] == 1).sum()) >= 3 and int((batch["lm_label_ids"] != -1).sum()) >= 2:
+                break
+            seed += 1
+        draws = None
+        if "2" in cd["visual_target_weights"]:
+            draws = R.nce_draws(seed=0x1234ABCD5, site=0, B=B, R=Rn)
+        blob_seed = seed
+        out, model = run_reference_variant(BertConfig, Model, cd, sd, batch, draws)
+        blob = {"cfg_json": np.array(json.dumps(cd)), "ref_keys": np.array(list(model.state_dict().keys())), "batch_seed": np.array([blob_seed])}
+        blob.update({"in::" + k: v.numpy() for k, v in batch.items()})
+        if draws is not None:
+            blob.update({"draw::" + k: v.numpy() for k, v in draws.items()})
+        blob["weights_seed"] = np.array([7])             # R.make_weights(cfg, seed=7): the 2048-wide tensors are not stored
+        for k, v in out.items():
+            if k.startswith("grad::") and v.size > 8192:   # large gradients: a slice and the norm
+                blob["out::gradslice::" + k[6:]] = v.reshape(v.shape[0], -1)[:16, :64]
+                blob["out::gradnorm::" + k[6:]] = np.array([np.sqrt((v.astype(np.float64) ** 2).sum())])
+            else:
+                blob["out::" + k] = v
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(name, "losses", out["loss_lm"], out["loss_img"], out["loss_nsp"], os.path.getsize(path) // 1024, "KB", "no grad:", list(out["grad_none"]))
+    # the two real non-ctrl configs that keep the 768-wide geometry, B=2 (weights from the seed generator, as write_ctrl)
+    for name, Rn in (("lxmert", 36), ("vl-bert_base", 36)):
+        cd = json.load(open(os.path.join(REF, "config", name + ".json")))
+        cfg = R.RefConfig(cd)
+        sd = R.make_weights(cfg, seed=3, std=0.03)
+        batch = R.synthetic_batch(cfg, B=2, T=20, R=Rn, seed=7)
+        out, model = run_reference_variant(BertConfig, Model, cd, sd, batch)
+        blob = {"cfg_json": np.array(json.dumps(cd)), "n_params": np.array([sum(p.numel() for p in model.parameters())]),
+                "ref_keys": np.array(list(model.state_dict().keys())), "out::grad_none": out["grad_none"]}
+        for k in ("loss_lm", "loss_img", "loss_nsp", "pooled_t", "pooled_v", "grad_norm"):
+            if k in out:
+                blob["out::" + k] = out[k]
+        blob["out::seq_t_slice"] = out["seq_t"][:, :, :64]
+        blob["out::seq_v_slice"] = out["seq_v"][:, :8, :64]
+        for k in VARIANT_GRAD_KEYS[1:]:
+            if "grad::" + k in out:
+                g = out["grad::" + k]
+                blob["out::gradslice::" + k] = g.reshape(g.shape[0], -1)[:16, :64] if g.ndim > 1 else g[:64]
+                blob["out::gradnorm::" + k] = np.array([np.sqrt((g.astype(np.float64) ** 2).sum())])
+        path = os.path.join(OUT, "full_" + name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(name, int(blob["n_params"][0]), "losses", out["loss_lm"], out["loss_img"], out["loss_nsp"], os.path.getsize(path) // 1024, "KB")
+        del model, sd
+
+
 def write_fullsize(BertConfig, Model):
     """ctrl_vilbert_base at the BASELINE batch (B=256, T=20, R=36; forward only) and at B=32 (forward + backward): the
     contract check of north_star's "loss matching reference to 1e-3 rel" at the size the bench line is quoted on, and
@@ -383,6 +529,8 @@ if __name__ == "__main__":
         write_tiny(BertConfig, Model)
     if which in ("all", "ctrl"):
         write_ctrl(BertConfig, Model)
+    if which in ("all", "variants"):
+        write_variants(BertConfig, Model)
     if which in ("all", "full"):
         write_fullsize(BertConfig, Model)
     if which in ("all", "init"):

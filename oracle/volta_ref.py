@@ -233,6 +233,8 @@ def emb_vlbert(sd, cfg, ids, feat, loc, type_ids, drop):
     final = torch.relu(linear(x, sd, pre + "obj_downsample.1")).view(B, K, -1)
     obj_vis = layer_norm(final, sd[pre + "visual_ln_object.weight"], sd[pre + "visual_ln_object.bias"])
     obj_ling = sd[pre + "object_linguistic_embeddings.weight"][0].expand(B, K, -1).clone()
+    if cfg.visual_target_weights.get("6", 0) > 0:      # with the xent_1601 target, masked regions get their own word (embeddings.py:191,262-263)
+        obj_ling = torch.where(zero_rows[..., None], sd[pre + "object_mask_word_embedding.weight"][0], obj_ling)
     obj_ling[:, -1] = sd[pre + "end_embedding.weight"][0]
     obj = obj_ling + obj_vis
     txt_vis = layer_norm(final[:, -1:].expand(B, T, -1), sd[pre + "visual_ln_text.weight"], sd[pre + "visual_ln_text.bias"])
@@ -657,6 +659,8 @@ def param_shapes(cfg):
     elif kind == "vl-bert":
         lin(e + "obj_downsample.1", Hv, 2 * F_)
         s[e + "object_linguistic_embeddings.weight"] = (1, H)
+        if cfg.visual_target_weights.get("6", 0) > 0:
+            s[e + "object_mask_word_embedding.weight"] = (1, H)
         s[e + "object_mask_visual_embedding.weight"] = (1, F_)
         s[e + "end_embedding.weight"] = (1, H)
         s[e + "word_embeddings.weight"] = (V, H)

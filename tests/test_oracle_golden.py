@@ -191,3 +191,81 @@ def test_philox_known_answer():
     assert int(u[1, 9]) == int(w[1])
     keep = R.philox_keep_mask(1234, 3, (1000, 100), 0.1)
     assert abs(float(keep.float().mean()) - 0.9) < 5e-3
+
+
+# ---- the other fusion methods / global-feature placements / visual targets
+VARIANTS = ["var_lxmert_text", "var_vlbert_none", "var_sum_mse_kl", "var_vqa_nce"]
+
+
+def _variant(z):
+    cfg = R.RefConfig(json.loads(str(z["cfg_json"])))
+    sd = {k: v.clone().requires_grad_(True) for k, v in R.make_weights(cfg, seed=int(z["weights_seed"][0])).items() if k in R.param_shapes(cfg)}
+    for alias, target in R.param_aliases(cfg).items():
+        sd[alias] = sd[target]
+    batch = {k[4:]: torch.from_numpy(v) for k, v in z.items() if k.startswith("in::")}
+    kw = {}
+    if "draw::row_across" in z:
+        draws = {k[6:]: torch.from_numpy(v) for k, v in z.items() if k.startswith("draw::")}
+        B, Rn = batch["image_label"].shape
+        # the stored draws ARE what nce_draws produces from the seed (the product's device generator is tested against the same function)
+        again = R.nce_draws(seed=0x1234ABCD5, site=0, B=B, R=Rn)
+        assert all(torch.equal(draws[k], again[k]) for k in draws)
+        kw["nce_index"] = R.nce_negative_index(draws, B, Rn)
+    return cfg, sd, batch, kw
+
+
+@pytest.mark.parametrize("name", VARIANTS)
+def test_variant_heads_match_reference(golden_dir, name):
+    """Text-only / sum / VL-BERT-VQA / no fusion, global feature last or absent, and the mse / nce / xent_1600 / xent_400 / huber /
+    xent_1601 targets (volta/losses.py:25-126) against the real model; nce_2048 through the harness shim described in make_golden.py."""
+    z = load(golden_dir, name)
+    cfg, sd, batch, kw = _variant(z)
+    assert set(R.param_shapes(cfg)) | set(R.param_aliases(cfg)) == set(str(k) for k in z["ref_keys"])
+    taps = {}
+    lm, img, nsp = R.forward_from_batch(sd, cfg, batch, taps=taps, **kw)
+    for got, key in ((lm, "loss_lm"), (img, "loss_img"), (nsp, "loss_nsp")):
+        np.testing.assert_allclose(got.detach().numpy(), z["out::" + key], rtol=3e-6, atol=2e-6)
+    for key in ("seq_t", "seq_v", "pooled_t", "pooled_v"):
+        if "out::" + key in z:
+            np.testing.assert_allclose(taps[key].detach().numpy(), z["out::" + key], rtol=0, atol=5e-6)
+        else:
+            assert taps[key] is None
+    (lm + img + nsp).sum().backward()
+    checked = 0
+    for k, v in z.items():
+        if k.startswith("out::grad::"):
+            g = sd[k[len("out::grad::"):]].grad.numpy()
+            np.testing.assert_allclose(g, v, rtol=0, atol=2e-6 + 2e-5 * np.abs(v).max())
+            checked += 1
+        elif k.startswith("out::gradslice::"):
+            g = sd[k[len("out::gradslice::"):]].grad.numpy()
+            np.testing.assert_allclose(g.reshape(g.shape[0], -1)[:16, :64], v, rtol=0, atol=2e-6 + 2e-5 * np.abs(v).max())
+            np.testing.assert_allclose(np.sqrt((g.astype(np.float64) ** 2).sum()), z["out::gradnorm::" + k[len("out::gradslice::"):]][0], rtol=2e-5)
+            checked += 1
+    assert checked >= 6
+    none = set(str(k) for k in z["out::grad_none"])
+    assert none == set(k for k, t in sd.items() if k in R.param_shapes(cfg) and t.grad is None)      # e.g. the VQA text pooler in pre-training
+    uniq = {id(t): t for t in sd.values()}
+    total = np.sqrt(sum(float((t.grad.double() ** 2).sum()) for t in uniq.values() if t.grad is not None))
+    np.testing.assert_allclose(total, z["out::grad_norm"][0], rtol=2e-5)
+
+
+@pytest.mark.parametrize("name", ["lxmert", "vl-bert_base"])
+def test_non_ctrl_config_matches_reference(golden_dir, name):
+    """config/lxmert.json (text fusion, xent_1600 + xent_400 + huber_2048) and config/vl-bert_base.json (no fusion, global feature last,
+    xent_1601 + the masked-region word embedding) at full width, B=2."""
+    z = load(golden_dir, "full_" + name)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = R.RefConfig.from_json_file(os.path.join(root, "config", name + ".json"))
+    shapes = R.param_shapes(cfg)
+    assert set(shapes) | set(R.param_aliases(cfg)) == set(str(k) for k in z["ref_keys"])
+    assert sum(int(np.prod(s)) for s in shapes.values()) == int(z["n_params"][0])
+    sd = R.make_weights(cfg, seed=3, std=0.03)
+    batch = R.synthetic_batch(cfg, B=2, T=20, R=36, seed=7)
+    taps = {}
+    with torch.no_grad():
+        lm, img, nsp = R.forward_from_batch(sd, cfg, batch, taps=taps)
+    for got, key in ((lm, "loss_lm"), (img, "loss_img"), (nsp, "loss_nsp")):
+        np.testing.assert_allclose(got.numpy(), z["out::" + key], rtol=2e-5, atol=1e-6)
+    np.testing.assert_allclose(taps["seq_t"].numpy()[:, :, :64], z["out::seq_t_slice"], rtol=0, atol=5e-5)
+    np.testing.assert_allclose(taps["seq_v"].numpy()[:, :8, :64], z["out::seq_v_slice"], rtol=0, atol=5e-5)
