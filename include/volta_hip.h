@@ -301,11 +301,59 @@ typedef struct vk_kl_args {
 } vk_kl_args;
 int vk_kl_fwd(const vk_kl_args* a, vk_stream_t s);
 int vk_kl_bwd(const vk_kl_args* a, void* dlogits, int ldd, const float* gscale, vk_stream_t s);
-/* losses[0] = sums[0] / *n_t ; losses[1] = w * sums[1] / max(*n_v, 1) ; losses[2] = sums[2] / B */
+/* losses[0] = sums[0] / *n_t ; losses[1] = w * sums[1] / max(*n_v, 1) ; losses[2] = sums[2] / B.  vk_kl_fwd and vk_vis_loss_fwd
+   accumulate WEIGHTED row losses (several targets share sums[1]), so the engine passes w = 1. */
 int vk_loss_finalize(const float* sums, const int32_t* n_t, const int32_t* n_v, int B, float kl_weight, float* losses, vk_stream_t s);
 /* pooled = dropout(pooled_t * pooled_v) (encoders.py:769-770) and its backward through the two ReLUs */
 int vk_pool_mul_fwd(const void* pt, const void* pv, void* out, int B, int P, vk_dropout drop, vk_stream_t s);
 int vk_pool_mul_bwd(const void* dp, int ldp, const void* pt, const void* pv, void* dyt, void* dyv, int B, int P, vk_dropout drop, vk_stream_t s);
+/* The other fusions of the two pooled vectors (BertPreTrainingHeads.forward / BertForVLTasks.forward, encoders.py:766-778,1184-1195):
+   out = dropout(pt * pv | pt + pv | pt); "text" and "vl-bert_vqa" have no vision pooler (pv, dyv NULL).  vk_pool_mul_* = mode VK_FUSE_MUL. */
+enum { VK_FUSE_MUL = 0, VK_FUSE_SUM = 1, VK_FUSE_TEXT = 2 };
+int vk_pool_fuse_fwd(const void* pt, const void* pv, void* out, int B, int P, int mode, vk_dropout drop, vk_stream_t s);
+int vk_pool_fuse_bwd(const void* dp, int ldp, const void* pt, const void* pv, void* dyt, void* dyv, int B, int P, int mode, vk_dropout drop, vk_stream_t s);
+/* VLBertTextPooler (encoders.py:610-623) pools the token two places before the end of the caption:
+   rows[b] = b * T + max(#non-zero ids of caption b - 2, 0), *count = B (feeds vk_gather_rows / vk_scatter_rows_add). */
+int vk_text_end_rows(const int64_t* ids, int B, int T, int32_t* rows, int32_t* count, vk_stream_t s);
+/* VL-BERT with the xent_1601 target gives masked regions (all-zero feature rows) a word of their own (embeddings.py:191,262-264):
+   ids[m] = 1 for the last region of a sample (END), 2 for a masked region, 0 otherwise -- the row of the 3-row word table. */
+int vk_vlbert_obj_ids(const int32_t* zero_flag, int64_t* ids, int M, int K, vk_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * The visual targets other than kl_1601 (volta/losses.py:25-126), on the labelled regions only.  Row i of `logits` is the
+ * decoder's prediction for the i-th masked region; pos[i] = its index in the [B, R] label grid (= row of target / labels / conf).
+ * Every kernel adds weight x row loss to *loss_sum; the image loss is loss_sum / max(*count, 1):
+ *   VK_VIS_MSE    mse_2048   (:25-33)     mean_c (x - feat)^2
+ *   VK_VIS_HUBER  huber_2048 (:105-113)   mean_c smooth_l1(x - feat)
+ *   VK_VIS_XENT   xent_1600 / xent_400 (:83-102, conf = detector confidence) and xent_1601 (:116-124, conf NULL)
+ *   VK_VIS_NCE    nce_2048   (:36-80)     lse_j <sample_j, x> - <sample_0, x>, sample_0 = the region's own feature,
+ *                                         samples 1..n_neg = target rows neg_index[pos * n_neg + j - 1] (vk_nce_negatives)
+ * The backward writes dlogits (bf16, columns [V, ldd) = 0) = d(loss_sum / max(count,1)) / d logits x *gscale.
+ * ---------------------------------------------------------------------------------------------- */
+enum { VK_VIS_MSE = 1, VK_VIS_NCE = 2, VK_VIS_XENT = 3, VK_VIS_HUBER = 5 };
+#define VK_NCE_ACROSS 89          /* int(128 * 0.7) negatives from other images of the batch (losses.py:45) */
+#define VK_NCE_INSIDE 38          /* int(128 * 0.3) negatives from the same image (losses.py:46) */
+#define VK_NCE_MAX_SAMPLES 128
+typedef struct vk_vis_loss_args {
+    const float* logits;       /* fp32 [rows, ld] */
+    const float* target;       /* regression / nce: the region features the model was given, fp32 [B*R, V] */
+    const int64_t* labels;     /* xent: [B*R] */
+    const float* conf;         /* xent: [B*R] or NULL */
+    const int32_t* pos;        /* [rows] */
+    const int32_t* count;      /* device row count */
+    const int32_t* neg_index;  /* nce: [B*R, n_neg] */
+    float* lse;                /* [rows] saved (xent, nce) */
+    float* aux;                /* nce: [rows, VK_NCE_MAX_SAMPLES] saved scores */
+    float* loss_sum;
+    float weight;              /* visual_target_weights[ix] */
+    int32_t V, ld, max_rows, kind, n_neg;
+} vk_vis_loss_args;
+int vk_vis_loss_fwd(const vk_vis_loss_args* a, vk_stream_t s);
+int vk_vis_loss_bwd(const vk_vis_loss_args* a, void* dlogits, int ldd, const float* gscale, vk_stream_t s);
+/* The 127 negatives of every region as losses.py:47-69 draws them, from the counter-based stream (rng.seed, rng.site):
+   out[(b*R + r) * 127 + j]; j < 89: a region of another image, j >= 89: another region of the same image.  B, R >= 2. */
+int vk_nce_negatives(vk_dropout rng, int B, int R, int32_t* out, vk_stream_t s);
+
 /* additive attention mask (1 - m) * -10000 (encoders.py:983-991) */
 int vk_mask_prep(const int64_t* mask, float* out, int n, vk_stream_t s);
 
@@ -397,8 +445,13 @@ enum {
     VK_FN_VLBERT_PREP, VK_FN_VLBERT_MASKGRAD, VK_FN_ROWGROUP_SUM, VK_FN_RELU_BWD, VK_FN_COPY, VK_FN_SUM_SLABS, VK_FN_SUM_SLABS_BF16,
     VK_FN_SIDE_TAIL,     /* p[0] = vk_tail_job[n[0]] */
     VK_FN_QUANT_ROWS,    /* vk_quant_rows_fp8(p[0], n[4], n[2], p[1], n[3], p[2], n[0], n[1], p[3]) */
-    VK_FN_CAST_FP8       /* vk_cast_bf16_fp8(p[0], p[1], n[0], f[0]) */
-};
+    VK_FN_CAST_FP8,      /* vk_cast_bf16_fp8(p[0], p[1], n[0], f[0]) */
+    VK_FN_VIS_LOSS_FWD,  /* vk_vis_loss_fwd(p[0]) */
+    VK_FN_VIS_LOSS_BWD,  /* vk_vis_loss_bwd(p[0], p[1], n[0], p[2]) */
+    VK_FN_NCE_NEG,       /* vk_nce_negatives(drop, n[0], n[1], p[0]) */
+    VK_FN_TEXT_END_ROWS, /* vk_text_end_rows(p[0], n[0], n[1], p[1], p[2]) */
+    VK_FN_VLBERT_OBJ_IDS /* vk_vlbert_obj_ids(p[0], p[1], n[0], n[1]) */
+};                       /* VK_FN_POOL_FWD / VK_FN_POOL_BWD: n[3] = fusion mode (VK_FUSE_*) */
 typedef struct vk_generic_args {   /* positional arguments of the small entry points, see executor.cpp */
     int32_t fn;
     void* p[6];

@@ -397,16 +397,19 @@ def write_tasks(BertConfig):
     predictions and the gradients of a few parameters for loss = sum(prediction * probe)."""
     import json
     from volta.encoders import BertForVLTasks
-    for name in ("tiny_vilbert", "tiny_uniter"):
-        cd = dict(tiny_configs()[name], clf_hidden_size=96)
+    variants = {"tiny_vilbert": {}, "tiny_uniter": {},
+                # the other fusion methods of the task model (encoders.py:1184-1195); vl-bert_vqa pools the token before the caption's end
+                "tiny_vilbert_vqa": dict(fusion_method="vl-bert_vqa"), "tiny_vilbert_sum": dict(fusion_method="sum"), "tiny_vilbert_text": dict(fusion_method="text")}
+    for name, extra in variants.items():
+        cd = dict(tiny_configs()[name[:12] if name.startswith("tiny_vilbert") else name], clf_hidden_size=96, **extra)
         cfg = R.RefConfig(cd)
-        ids = list(TASK_CFG)
+        ids = list(TASK_CFG) if not extra else ["TASK1", "TASK9", "TASK12"]
         sd = R.make_task_weights(cfg, TASK_CFG, ids, seed=13)
         batch = R.synthetic_batch(cfg, B=4, T=6, R=4, seed=17, pad=True)
         model = BertForVLTasks(BertConfig.from_dict(cd), TASK_CFG, ids)
         model.load_state_dict(sd, strict=True)
         model.eval()
-        blob = {"cfg_json": np.array(json.dumps(cd)), "task_cfg_json": np.array(json.dumps(TASK_CFG)), "ref_keys": np.array(list(model.state_dict().keys()))}
+        blob = {"cfg_json": np.array(json.dumps(cd)), "task_cfg_json": np.array(json.dumps({t: TASK_CFG[t] for t in ids})), "ref_keys": np.array(list(model.state_dict().keys()))}
         for t in ids:
             model.zero_grad()
             pred = model(batch["input_ids"], batch["image_feat"].clone(), batch["image_loc"], t, batch["segment_ids"], batch["input_mask"], batch["image_mask"])[0]
@@ -417,7 +420,7 @@ def write_tasks(BertConfig):
             named = dict(model.named_parameters())
             for k in ("bert.encoder.layer.0.attention_self.query.weight", "bert.embeddings.word_embeddings.weight", "bert.t_pooler.dense.weight",
                       "bert.v_pooler.dense.bias", [q for q in named if q.startswith("clfs_dict.%s." % t)][0]):
-                if named[k].grad is not None:
+                if k in named and named[k].grad is not None:
                     blob["grad::%s::%s" % (t, k)] = named[k].grad.numpy().copy()
         path = os.path.join(OUT, "tasks_" + name + ".npz")
         np.savez_compressed(path, **blob)

@@ -501,10 +501,10 @@ def visual_losses(cfg, scores_v, image_label, image_cls=None, image_feat=None, o
     """encoders.py:1079-1087: sum of the configured targets' losses; a target whose inputs are missing contributes 0."""
     total = torch.zeros(())
     for ix, w in cfg.visual_target_weights.items():
+        if not w > 0:        # (the reference has no decoder for such an entry and fails on it, encoders.py:1080-1084)
+            continue
         sv = scores_v[ix]
         sv = sv[:, :-1] if cfg.add_global_imgfeat == "last" else sv[:, int(cfg.add_global_imgfeat is not None):]
-        if not w > 0:
-            continue
         if ix == "0" and image_cls is not None:
             total = total + kl_1601(sv, w, image_label, image_cls)
         elif ix == "1" and image_feat is not None:
@@ -539,7 +539,7 @@ def pretrain_forward(sd, cfg, input_ids, image_feat, image_loc, token_type_ids=N
     hv = gelu(linear(v, sd, ci + "transform.dense"))
     if cfg.image_head_ln:
         hv = layer_norm(hv, sd[ci + "transform.LayerNorm.weight"], sd[ci + "transform.LayerNorm.bias"])
-    scores_v = {ix: linear(hv, sd, ci + "decoder_dict." + ix) for ix in cfg.visual_target_weights}
+    scores_v = {ix: linear(hv, sd, ci + "decoder_dict." + ix) for ix, w in cfg.visual_target_weights.items() if w > 0}
     # the ITM head exists unless the fusion method is "none" / "vl-bert_vqa" (encoders.py:744-747)
     itm = linear(pooled, sd, "cls.bi_seq_relationship") if cfg.fusion_method not in ("none", "vl-bert_vqa") else None
     if taps is not None:
@@ -715,8 +715,9 @@ def param_shapes(cfg):
     lin("cls.imagePredictions.transform.dense", Hv, Hv)
     if cfg.image_head_ln:
         ln("cls.imagePredictions.transform.LayerNorm", Hv)
-    for ix, w in cfg.visual_target_weights.items():          # encoders.py:718-723: one decoder per target, in the config's order
-        lin("cls.imagePredictions.decoder_dict." + ix, VIS_TARGET_WIDTH[ix], Hv)
+    for ix, width in VIS_TARGET_WIDTH.items():               # encoders.py:725-729: one decoder per target with a positive weight, in
+        if cfg.visual_target_weights.get(ix, 0) > 0:          # the order of losses.py's table (not the config's)
+            lin("cls.imagePredictions.decoder_dict." + ix, width, Hv)
     return s
 
 

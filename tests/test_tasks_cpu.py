@@ -19,7 +19,7 @@ def _load(name):
     return z, cd, task_cfg
 
 
-@pytest.mark.parametrize("name", ["tiny_vilbert", "tiny_uniter"])
+@pytest.mark.parametrize("name", ["tiny_vilbert", "tiny_uniter", "tiny_vilbert_vqa", "tiny_vilbert_sum", "tiny_vilbert_text"])
 def test_oracle_tasks_forward_backward_matches_reference(name):
     z, cd, task_cfg = _load(name)
     cfg = R.RefConfig(cd)

@@ -17,16 +17,22 @@ def rel(a, b):
     return float((a - b).norm() / (b.norm() + 1e-12))
 
 
-@pytest.mark.parametrize("cfg_name", ["vilbert", "uniter"])
+@pytest.mark.parametrize("cfg_name", ["vilbert", "uniter", "vilbert:vl-bert_vqa", "vilbert:sum", "vilbert:text"])
 def test_task_heads_forward_backward_parity(cfg_name):
+    """`name:fusion` runs the other fusion methods of the task model (encoders.py:1184-1195): sum, text-only, and vl-bert_vqa, whose
+    text pooler (VLBertTextPooler, :610-623) takes the token two places before each caption's end -- gathered and pooled by the engine."""
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     from test_engine_gpu import CONFIGS
     from oracle import volta_ref as R
     from volta_amd.config import BertConfig
     from volta_amd.modeling import BertForVLTasks
+    cfg_name, _, fusion = cfg_name.partition(":")
     cd = dict(CONFIGS[cfg_name], clf_hidden_size=1536)
-    rcfg = R.RefConfig(cd)
     ids = list(TASK_CFG)
+    if fusion:
+        cd["fusion_method"] = fusion
+        ids = ["TASK1", "TASK9", "TASK12"]
+    rcfg = R.RefConfig(cd)
     sd = R.make_task_weights(rcfg, TASK_CFG, ids, seed=4, std=0.04)
     model = BertForVLTasks(BertConfig.from_dict(cd), TASK_CFG, ids)
     model.load_state_dict(sd, strict=True)

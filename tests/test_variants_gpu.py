@@ -1,0 +1,211 @@
+"""SURVEY.md 8f-4 on the HIP engine: the other fusion methods (sum / text / vl-bert_vqa / none), global feature last or absent, the
+mse / nce / xent_1600 / xent_400 / huber / xent_1601 visual targets (volta/losses.py:25-126) and VL-BERT's masked-region word -- at
+true width against the oracle (which tests/test_oracle_golden.py pins to the real model on the var_* fixtures), and the two real
+non-ctrl configs that keep the 768-wide geometry (config/lxmert.json, config/vl-bert_base.json) against fixtures of the real model."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import volta_ref as R
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+BASE = dict(vocab_size=3000, hidden_size=768, num_attention_heads=12, intermediate_size=3072, pooler_size=1024,
+            max_position_embeddings=64, type_vocab_size=2, num_locs=5, add_global_imgfeat="first", v_feature_size=256,
+            v_hidden_size=768, v_num_attention_heads=12, v_intermediate_size=3072, v_pooler_size=1024,
+            visual_target_weights={"0": 1.0}, fusion_method="mul", v_initializer_range=0.02)
+ENC = dict(tt_attn_sublayers=[0, 4], t_ff_sublayers=[1, 3, 5], tv_attn_sublayers=[2], vt_attn_sublayers=[2], vv_attn_sublayers=[4], v_ff_sublayers=[3, 5])
+SINGLE = dict(tt_attn_sublayers=[0, 2], tv_attn_sublayers=[0, 2], vt_attn_sublayers=[0, 2], vv_attn_sublayers=[0, 2],
+              t_ff_sublayers=[1, 3], v_ff_sublayers=[1, 3], shared_sublayers=[0, 1, 2, 3], single_ln_sublayers=[0, 1, 2, 3])
+BIG = dict(BASE, v_feature_size=2048)
+VARIANTS = {
+    "lxmert_text": dict(BIG, image_embeddings="lxmert", fusion_method="text", add_global_imgfeat=None, num_locs=4, pooler_size=768,
+                        visual_target_weights={"3": 6.667, "4": 6.667, "5": 6.667},
+                        tt_attn_sublayers=[0, 2, 5], vv_attn_sublayers=[0, 5], tv_attn_sublayers=[4], vt_attn_sublayers=[4],
+                        shared_sublayers=[4], t_ff_sublayers=[1, 3, 6], v_ff_sublayers=[1, 6]),
+    "vlbert_none": dict(BASE, image_embeddings="vl-bert", type_vocab_size=3, image_head_ln=False, v_coordinate_embeddings_dim=32,
+                        fusion_method="none", add_global_imgfeat="last", num_locs=4, pooler_size=None, v_pooler_size=None,
+                        visual_target_weights={"6": 1.0}, **SINGLE),
+    "sum_mse_kl": dict(BIG, image_embeddings="vilbert", fusion_method="sum", add_global_imgfeat=None,
+                       visual_target_weights={"1": 2.0, "0": 0.5}, **ENC),
+    "vqa_nce": dict(BIG, image_embeddings="vilbert", fusion_method="vl-bert_vqa", add_global_imgfeat=None,
+                    visual_target_weights={"2": 1.5}, **ENC),
+    "mul_last_two": dict(BASE, image_embeddings="uniter", add_global_imgfeat="last", visual_target_weights={"6": 0.7, "0": 1.0}, **SINGLE),
+}
+
+
+def rel_err(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-12))
+
+
+def build(cd, seed=2, std=0.04):
+    from volta_amd.config import BertConfig
+    from volta_amd.modeling import BertForVLPreTraining
+    rcfg = R.RefConfig(cd)
+    sd = R.make_weights(rcfg, seed=seed, std=std)
+    model = BertForVLPreTraining(BertConfig.from_dict(cd))
+    assert set(model.state_dict().keys()) == set(sd.keys())
+    model.load_state_dict(sd, strict=True)
+    return model.cuda(), rcfg, sd
+
+
+def run_model(model, cb):
+    return model(cb["input_ids"], cb["image_feat"], cb["image_loc"], cb["segment_ids"], cb["input_mask"], cb["image_mask"], cb["lm_label_ids"],
+                 cb["image_label"], cb["image_cls"], cb.get("obj_labels"), cb.get("obj_confs"), cb.get("attr_labels"), cb.get("attr_confs"), None, cb["is_match"])
+
+
+@pytest.mark.parametrize("train", [False, True])
+@pytest.mark.parametrize("name", list(VARIANTS))
+def test_variant_forward_backward_parity(name, train):
+    cd = VARIANTS[name]
+    model, rcfg, sd = build(cd)
+    B, T, Rn = 4, 20, 36
+    bseed = 7
+    while True:                                      # a batch that keeps a few masked regions after the objective-1 relabel
+        batch = R.synthetic_batch(rcfg, B, T, Rn, seed=bseed, pad=True)
+        if int((batch["image_label"] == 1).sum()) >= 6:
+            break
+        bseed += 1
+    seed = 0xABCDEF12345
+    model.train(train)
+    model.set_dropout_seed(seed)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    lm, img, nsp = run_model(model, cb)
+    torch.cuda.synchronize()
+    eng = model._last[0]
+    aliases = R.param_aliases(rcfg)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k not in aliases}
+    full = dict(leaves)
+    for a, t in aliases.items():
+        full[a] = leaves[t]
+    kw = {}
+    if "2" in cd["visual_target_weights"]:
+        # the device's negatives: same counter-based stream as the oracle's generator, bit for bit
+        draws = R.nce_draws(seed, eng.nce_site, B, Rn)
+        want_idx = R.nce_negative_index(draws, B, Rn)
+        got_idx = eng.bufs["img_nce_neg"].cpu().view(B, Rn, -1).long()
+        assert torch.equal(got_idx, want_idx)
+        kw["nce_index"] = want_idx
+    taps = {}
+    olm, oimg, onsp = R.forward_from_batch(full, rcfg, batch, train=train, philox_seed=seed if train else None, taps=taps, **kw)
+    for key, ref in taps.items():
+        if key not in eng.taps or ref is None or not torch.is_tensor(ref) or ref.dim() < 2:
+            continue
+        if eng.taps[key] is None:
+            continue
+        e = rel_err(eng.taps[key].float().cpu().view(ref.shape), ref.detach())
+        assert e < 2e-2, (name, key, e)
+    for got, ref, nm in ((lm, olm, "lm"), (img, oimg, "img"), (nsp, onsp, "nsp")):
+        g, r = float(got.detach()), float(ref.detach())
+        # the regression / nce targets square or exponentiate bf16-rounded 2048-wide predictions: 3e-3; hard-label targets as the MLM loss
+        tol = 1e-2 if nm == "nsp" else (3e-3 if nm == "img" else 1.5e-3)      # MLM at B = 4: 1.1e-3 observed for one variant in training mode
+        assert abs(g - r) <= tol * max(abs(r), 1e-3) + 1e-4, (name, nm, g, r)
+    assert float(oimg.detach()) > 0
+    named = dict(model.named_parameters())
+    (lm + img + nsp).sum().backward()
+    (olm + oimg + onsp).sum().backward()
+    torch.cuda.synchronize()
+    bad = []
+    # feature-regression / nce targets: d loss / d prediction = (prediction - feature) or a softmax over <feature, prediction>, both differences
+    # of quantities that carry the bf16 noise of the 2048-wide prediction -- observed 4.5-5.6e-2 / cosine 0.9984 where the
+    # hard-label targets give 1e-2 / 0.9999
+    regress = bool(set(cd["visual_target_weights"]) & {"1", "2", "5"})
+    tol, min_cos = (8e-2, 0.997) if regress else (6e-2, 0.998)      # two-target uniter variant in training mode: 4.7e-2 / 0.9989 observed
+    for k, leaf in leaves.items():
+        if leaf.grad is None:                      # the reference's autograd leaves these parameters alone: so must the engine
+            assert named[k].grad is None, (name, k)
+            continue
+        assert named[k].grad is not None, (name, k)
+        g_ref, g_got = leaf.grad, named[k].grad.float().cpu()
+        assert torch.isfinite(g_got).all(), (name, k)
+        # key biases: identically zero by the softmax's shift invariance (the reference leaves 1e-6-sized rounding residue); the engine's residue
+        # is the column sum of bf16-rounded dK rows -- bounded against the query bias of the same sub-layer, whose gradient is the same kind of sum
+        scale = float(leaves[k.replace("key.", "query.")].grad.norm()) if k.endswith("key.bias") else 0.0
+        if float(g_ref.norm()) < 1e-6 + 1e-4 * scale:
+            if float(g_got.norm()) > 5e-3 + 0.3 * scale:
+                bad.append((k, "expected ~0", float(g_got.norm()), scale))
+            continue
+        e = rel_err(g_got, g_ref)
+        cos = float((g_got * g_ref).sum() / (g_got.norm() * g_ref.norm()))
+        itm_only = k.startswith(("bert.t_pooler", "bert.v_pooler", "cls.bi_seq"))
+        qk = "query." in k or "key." in k
+        if e > (0.5 if itm_only else max(0.1, tol) if qk else tol) or cos < (0.9 if itm_only else 0.995 if qk else min_cos):
+            bad.append((k, e, cos, float(g_ref.norm())))
+    assert not bad, (name, train, bad[:12], len(bad))
+
+
+def test_variant_training_step_skips_unused_parameters():
+    """vl-bert_vqa in pre-training: the text pooler has no gradient (reference fixture: grad None); clip + AdamW leave it and its moments alone."""
+    from volta_amd.optimization import AdamW, clip_grad_norm_
+    model, rcfg, sd = build(VARIANTS["vqa_nce"])
+    model.train()
+    model.set_dropout_seed(5)
+    opt = AdamW([{"params": [p], "weight_decay": 0.01} for p in model.parameters()], lr=1e-3)
+    cb = {k: v.cuda() for k, v in R.synthetic_batch(rcfg, 4, 20, 36, seed=7).items()}
+    before = {k: p.detach().clone() for k, p in model.named_parameters()}
+    first = None
+    for _ in range(3):
+        out = run_model(model, cb)
+        sum(out).sum().backward()
+        clip_grad_norm_(model.parameters(), 5.0)
+        opt.step()
+        opt.zero_grad()
+        first = first if first is not None else [float(x) for x in out]
+    last = [float(x) for x in out]
+    torch.cuda.synchronize()
+    after = dict(model.named_parameters())
+    assert torch.equal(after["bert.t_pooler.dense.weight"].detach(), before["bert.t_pooler.dense.weight"])
+    assert not torch.equal(after["cls.imagePredictions.decoder_dict.2.weight"].detach(), before["cls.imagePredictions.decoder_dict.2.weight"])
+    assert last[0] + last[1] < first[0] + first[1] and last[2] == 0.0
+
+
+@pytest.mark.parametrize("name", ["lxmert", "vl-bert_base"])
+def test_non_ctrl_config_matches_reference_fixture(golden_dir, name):
+    from volta_amd.config import BertConfig
+    from volta_amd.modeling import BertForVLPreTraining
+    z = np.load(os.path.join(golden_dir, "full_" + name + ".npz"))
+    path = os.path.join(ROOT, "config", name + ".json")
+    rcfg = R.RefConfig(json.load(open(path)))
+    sd = R.make_weights(rcfg, seed=3, std=0.03)
+    model = BertForVLPreTraining(BertConfig.from_json_file(path))
+    assert list(model.state_dict().keys()) == [str(k) for k in z["ref_keys"]]
+    assert sum(p.numel() for p in model.parameters()) == int(z["n_params"][0])
+    model.load_state_dict(sd, strict=True)
+    model.cuda().eval()
+    cb = {k: v.cuda() for k, v in R.synthetic_batch(rcfg, B=2, T=20, R=36, seed=7).items()}
+    lm, img, nsp = run_model(model, cb)
+    (lm + img + nsp).sum().backward()
+    torch.cuda.synchronize()
+    report = {}
+    for got, key in ((lm, "loss_lm"), (img, "loss_img"), (nsp, "loss_nsp")):
+        want = float(z["out::" + key][0])
+        report[key] = abs(float(got) - want) / max(abs(want), 1e-6) if want else abs(float(got))
+    eng = model._last[0]
+    H = 768
+    report["seq_t"] = rel_err(eng.taps["seq_t"].float().cpu().view(2, 20, H)[:, :, :64], torch.from_numpy(z["out::seq_t_slice"]))
+    Rv = eng.Rv
+    report["seq_v"] = rel_err(eng.taps["seq_v"].float().cpu().view(2, Rv, H)[:, :8, :64], torch.from_numpy(z["out::seq_v_slice"]))
+    # B = 2: MLM / region losses 1.5e-3 (as the ctrl fixtures at B = 2), ITM 3e-2 (two samples of bf16-noisy logits)
+    assert report["loss_lm"] <= 1.5e-3 and report["loss_img"] <= 3e-3 and report["loss_nsp"] <= 3e-2, report
+    assert report["seq_t"] <= 2e-2 and report["seq_v"] <= 2e-2, report
+    named = dict(model.named_parameters())
+    none = set(str(k) for k in z["out::grad_none"])
+    assert none == {k for k, p in named.items() if p.grad is None}
+    for k in z.files:
+        if not k.startswith("out::gradslice::"):
+            continue
+        pname = k[len("out::gradslice::"):]
+        g = named[pname].grad.float().cpu().numpy()
+        gn = float(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        want_n = float(z["out::gradnorm::" + pname][0])
+        gs = g.reshape(g.shape[0], -1)[:16, :64] if g.ndim > 1 else g[:64]
+        cos = float((gs.ravel() @ z[k].ravel()) / (np.linalg.norm(gs) * np.linalg.norm(z[k]) + 1e-30))
+        itm = pname in ("bert.t_pooler.dense.weight", "cls.bi_seq_relationship.weight")
+        assert abs(gn - want_n) / want_n <= (0.1 if itm else 3e-2) and cos >= (0.98 if itm else 0.995), (pname, gn, want_n, cos)
+    total = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
+    assert abs(total - float(z["out::grad_norm"][0])) / float(z["out::grad_norm"][0]) <= 1e-2, report
+    print(name, {k: float("%.2e" % v) for k, v in report.items()})

@@ -38,6 +38,11 @@ def dropout_cfg(seed_ptr, site, p):
     return Dropout(seed_ptr, site, min(int(p * 4294967296.0), 0xFFFFFFFF), 1.0 / (1.0 - p))
 
 
+def rng_cfg(seed_ptr, site):
+    """A counter-based stream without a keep threshold (vk_nce_negatives): the seed word and the site id only."""
+    return Dropout(seed_ptr, site, 0, 1.0)
+
+
 class GemmProblem(C.Structure):
     _fields_ = [("A", c_p), ("B", c_p), ("C", c_p), ("C2", c_p), ("bias", c_p), ("R", c_p), ("bias_grad", c_p),
                 ("dyn", c_p), ("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32), ("ldc", i32),
@@ -95,6 +100,17 @@ class KlArgs(C.Structure):
                 ("loss_sum", c_p), ("weight", C.c_float), ("V", i32), ("ld", i32), ("max_rows", i32)]
 
 
+class VisLossArgs(C.Structure):
+    _fields_ = [("logits", c_p), ("target", c_p), ("labels", c_p), ("conf", c_p), ("pos", c_p), ("count", c_p), ("neg_index", c_p),
+                ("lse", c_p), ("aux", c_p), ("loss_sum", c_p), ("weight", C.c_float), ("V", i32), ("ld", i32), ("max_rows", i32),
+                ("kind", i32), ("n_neg", i32)]
+
+
+VIS_MSE, VIS_NCE, VIS_XENT, VIS_HUBER = 1, 2, 3, 5
+NCE_ACROSS, NCE_INSIDE, NCE_MAX_SAMPLES = 89, 38, 128
+FUSE_MUL, FUSE_SUM, FUSE_TEXT = 0, 1, 2
+
+
 class AdamwArgs(C.Structure):
     _fields_ = [("p", c_p), ("g", c_p), ("m", c_p), ("v", c_p), ("shadow", c_p), ("chunk_class", c_p), ("clip", c_p),
                 ("n", C.c_int64), ("cls_lr_mult", C.c_float * 8), ("cls_wd", C.c_float * 8), ("lr", C.c_float),
@@ -122,7 +138,8 @@ class Op(C.Structure):
  OP_KL_FWD, OP_KL_BWD, OP_GENERIC, OP_SIDE_BEGIN, OP_SIDE_END, OP_WAIT_SIDE, OP_JOIN, OP_LN_FINALIZE, OP_GEMM_FP8) = range(1, 19)
 (FN_CAST, FN_MEMSET, FN_LOC_FWD, FN_LOC_BWD, FN_ADD_DROPOUT, FN_COLSUM, FN_SELECT, FN_GATHER, FN_SCATTER_ADD,
  FN_LOSS_FINAL, FN_POOL_FWD, FN_POOL_BWD, FN_MASK_PREP, FN_MUL, FN_VLBERT_PREP, FN_VLBERT_MASKGRAD, FN_ROWGROUP_SUM,
- FN_RELU_BWD, FN_COPY, FN_SUM_SLABS, FN_SUM_SLABS_BF16, FN_SIDE_TAIL, FN_QUANT_ROWS, FN_CAST_FP8) = range(1, 25)
+ FN_RELU_BWD, FN_COPY, FN_SUM_SLABS, FN_SUM_SLABS_BF16, FN_SIDE_TAIL, FN_QUANT_ROWS, FN_CAST_FP8, FN_VIS_LOSS_FWD, FN_VIS_LOSS_BWD,
+ FN_NCE_NEG, FN_TEXT_END_ROWS, FN_VLBERT_OBJ_IDS) = range(1, 30)
 
 
 class AttnArgs(C.Structure):
@@ -182,6 +199,13 @@ _sig("vk_kl_fwd", C.c_int, C.POINTER(KlArgs), c_p)
 _sig("vk_kl_bwd", C.c_int, C.POINTER(KlArgs), c_p, C.c_int, c_p, c_p)
 _sig("vk_loss_finalize", C.c_int, c_p, c_p, c_p, C.c_int, C.c_float, c_p, c_p)
 _sig("vk_pool_mul_fwd", C.c_int, c_p, c_p, c_p, C.c_int, C.c_int, Dropout, c_p)
+_sig("vk_pool_fuse_fwd", C.c_int, c_p, c_p, c_p, C.c_int, C.c_int, C.c_int, Dropout, c_p)
+_sig("vk_pool_fuse_bwd", C.c_int, c_p, C.c_int, c_p, c_p, c_p, c_p, C.c_int, C.c_int, C.c_int, Dropout, c_p)
+_sig("vk_text_end_rows", C.c_int, c_p, C.c_int, C.c_int, c_p, c_p, c_p)
+_sig("vk_vlbert_obj_ids", C.c_int, c_p, c_p, C.c_int, C.c_int, c_p)
+_sig("vk_vis_loss_fwd", C.c_int, C.POINTER(VisLossArgs), c_p)
+_sig("vk_vis_loss_bwd", C.c_int, C.POINTER(VisLossArgs), c_p, C.c_int, c_p, c_p)
+_sig("vk_nce_negatives", C.c_int, Dropout, C.c_int, C.c_int, c_p, c_p)
 _sig("vk_pool_mul_bwd", C.c_int, c_p, C.c_int, c_p, c_p, c_p, c_p, C.c_int, C.c_int, Dropout, c_p)
 _sig("vk_mask_prep", C.c_int, c_p, c_p, C.c_int, c_p)
 _sig("vk_mul_bf16", C.c_int, c_p, c_p, c_p, C.c_int64, c_p, C.c_int, c_p)
@@ -210,6 +234,7 @@ EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_c
            "vk_add_dropout", "vk_colsum_bf16", "vk_vlbert_prep_fwd", "vk_vlbert_maskgrad", "vk_rowgroup_sum_bf16",
            "vk_relu_bwd_bf16", "vk_copy_async", "vk_select_rows", "vk_gather_rows", "vk_scatter_rows_add", "vk_xent_fwd",
            "vk_xent_bwd", "vk_kl_fwd", "vk_kl_bwd", "vk_loss_finalize", "vk_pool_mul_fwd", "vk_pool_mul_bwd",
+           "vk_pool_fuse_fwd", "vk_pool_fuse_bwd", "vk_text_end_rows", "vk_vlbert_obj_ids", "vk_vis_loss_fwd", "vk_vis_loss_bwd", "vk_nce_negatives",
            "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_grad_norm_clip_masked", "vk_adamw_step",
            "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_side_tail", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_join_from", "vk_side_enable", "vk_concap_batch"]
 

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     constexpr int NKT[2] = {TP / 16, RP / 16};
     const uint32_t kimg[2] = {lds0, lds0 + TP * 128};
     const uint32_t vimg[2] = {lds0 + (TP + RP) * 128, lds0 + (TP + RP) * 128 + TP * 128};
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
     const int b = blockIdx.x / a.nh, h = blockIdx.x - b * a.nh;
     const int g = lane >> 4, lq = lane & 15;
 
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     float VK_LDS* lse_s = (float VK_LDS*)(uintptr_t)(lds0 + 4 * ROWS * 128);
     float VK_LDS* del_s = lse_s + ROWS;
     const int rbase[2] = {0, TP};
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwaves = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
     const int b = blockIdx.x / a.nh, h = blockIdx.x - b * a.nh;
     const int g = lane >> 4, lq = lane & 15;
 

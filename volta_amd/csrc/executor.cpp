@@ -158,8 +158,13 @@ static int run_one(const vk_op& o, int i, vk_stream_t s) {
                     case VK_FN_GATHER: rc = vk_gather_rows(g->p[0], (const int32_t*)g->p[1], (const int32_t*)g->p[2], g->p[3], (int)g->n[0], (int)g->n[1], s); break;
                     case VK_FN_SCATTER_ADD: rc = vk_scatter_rows_add(g->p[0], (const int32_t*)g->p[1], (const int32_t*)g->p[2], g->p[3], (int)g->n[0], (int)g->n[1], s); break;
                     case VK_FN_LOSS_FINAL: rc = vk_loss_finalize((const float*)g->p[0], (const int32_t*)g->p[1], (const int32_t*)g->p[2], (int)g->n[0], g->f[0], (float*)g->p[3], s); break;
-                    case VK_FN_POOL_FWD: rc = vk_pool_mul_fwd(g->p[0], g->p[1], g->p[2], (int)g->n[0], (int)g->n[1], g->drop, s); break;
-                    case VK_FN_POOL_BWD: rc = vk_pool_mul_bwd(g->p[0], (int)g->n[2], g->p[1], g->p[2], g->p[3], g->p[4], (int)g->n[0], (int)g->n[1], g->drop, s); break;
+                    case VK_FN_POOL_FWD: rc = vk_pool_fuse_fwd(g->p[0], g->p[1], g->p[2], (int)g->n[0], (int)g->n[1], (int)g->n[3], g->drop, s); break;
+                    case VK_FN_POOL_BWD: rc = vk_pool_fuse_bwd(g->p[0], (int)g->n[2], g->p[1], g->p[2], g->p[3], g->p[4], (int)g->n[0], (int)g->n[1], (int)g->n[3], g->drop, s); break;
+                    case VK_FN_VIS_LOSS_FWD: rc = vk_vis_loss_fwd((const vk_vis_loss_args*)g->p[0], s); break;
+                    case VK_FN_VIS_LOSS_BWD: rc = vk_vis_loss_bwd((const vk_vis_loss_args*)g->p[0], g->p[1], (int)g->n[0], (const float*)g->p[2], s); break;
+                    case VK_FN_NCE_NEG: rc = vk_nce_negatives(g->drop, (int)g->n[0], (int)g->n[1], (int32_t*)g->p[0], s); break;
+                    case VK_FN_TEXT_END_ROWS: rc = vk_text_end_rows((const int64_t*)g->p[0], (int)g->n[0], (int)g->n[1], (int32_t*)g->p[1], (int32_t*)g->p[2], s); break;
+                    case VK_FN_VLBERT_OBJ_IDS: rc = vk_vlbert_obj_ids((const int32_t*)g->p[0], (int64_t*)g->p[1], (int)g->n[0], (int)g->n[1], s); break;
                     case VK_FN_MASK_PREP: rc = vk_mask_prep((const int64_t*)g->p[0], (float*)g->p[1], (int)g->n[0], s); break;
                     case VK_FN_MUL: rc = vk_mul_bf16(g->p[0], g->p[1], g->p[2], g->n[0], (const int32_t*)g->p[3], (int)g->n[1], s); break;
                     case VK_FN_VLBERT_PREP: rc = vk_vlbert_prep_fwd((const float*)g->p[0], (int)g->n[3], (const float*)g->p[1], (const float*)g->p[2], g->p[3], (int32_t*)g->p[4], (int)g->n[0], (int)g->n[1], (int)g->n[2], g->drop, s); break;

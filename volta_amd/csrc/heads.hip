@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void kl_fwd_kernel(vk_kl_args a) {
     }
     kl = block_sum(kl, sh);
     ts = block_sum(ts, sh);
-    if (threadIdx.x == 0) { a.lse[i] = lse; a.tsum[i] = ts; atomicAdd(a.loss_sum, kl); }
+    if (threadIdx.x == 0) { a.lse[i] = lse; a.tsum[i] = ts; atomicAdd(a.loss_sum, a.weight * kl); }      // weighted: several targets share the accumulator
 }
 __global__ __launch_bounds__(256) void kl_bwd_kernel(vk_kl_args a, uint16_t* dlogits, int ldd, const float* gscale) {
     const int i = blockIdx.x;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void kl_bwd_kernel(vk_kl_args a, uint16_t* dlo
 }
 
 // losses[0] = lm_sum / n_t (NaN when no labelled token, like the reference's mean over an empty set);
-// losses[1] = w * kl_sum / max(n_v, 1) ; losses[2] = itm_sum / B
+// losses[1] = w * region_sum / max(n_v, 1) (region_sum already carries the targets' weights: w = 1) ; losses[2] = itm_sum / B
 __global__ void loss_finalize_kernel(const float* sums, const int32_t* n_t, const int32_t* n_v, int B, float w, float* losses) {
     if (threadIdx.x == 0) {
         losses[0] = sums[0] / (float)(*n_t);

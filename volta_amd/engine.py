@@ -24,6 +24,7 @@ from ._lib import check, ptr
 from .modules import sublayer_schedule
 
 CHUNK = 1024
+VIS_TARGET_WIDTH = {"0": 1601, "1": 2048, "2": 2048, "3": 1600, "4": 400, "5": 2048, "6": 1601}      # volta/losses.py:129-137
 NO_DECAY = ("bias", "LayerNorm.bias", "LayerNorm.weight")
 
 
@@ -249,10 +250,11 @@ class StepEngine:
         if cfg.sublayer2attn_hidden_size or cfg.sublayer2num_attention_heads or cfg.sublayer2intermediate_size or \
                 cfg.sublayer2v_attn_hidden_size or cfg.sublayer2v_num_attention_heads or cfg.sublayer2v_intermediate_size:
             raise NotImplementedError("per-sub-layer sizes (non-ctrl configs) are out of scope (SURVEY.md 8f-4)")
-        if cfg.hidden_act != "gelu" or cfg.v_hidden_act != "gelu" or cfg.fusion_method != "mul":
-            raise NotImplementedError("engine supports gelu activations and 'mul' fusion (all ctrl_* configs)")
-        if heads == "pretrain" and [k for k, w in cfg.visual_target_weights.items() if w > 0] != ["0"]:
-            raise NotImplementedError("only visual target '0' (kl_1601) is on the hot path (SURVEY.md 2.1 #4)")
+        if cfg.hidden_act != "gelu" or cfg.v_hidden_act != "gelu":
+            raise NotImplementedError("engine supports gelu activations (every reference config)")
+        if cfg.fusion_method not in ("mul", "sum", "text", "vl-bert_vqa", "none"):
+            raise ValueError("Invalid fusion method: %s" % cfg.fusion_method)
+        self.unused_params = set()    # parameters no launch of this plan reads: their .grad stays None, as under the reference's autograd
         if T > 64 or Rv > 128:
             raise NotImplementedError("sequence lengths above (64, 128) exceed the attention tile budget")
         self.H, self.I, self.nh = H, cfg.intermediate_size, cfg.num_attention_heads
@@ -683,8 +685,10 @@ class StepEngine:
         T, K = st_t.L, st_v.L
         F_, dim = cfg.v_feature_size, cfg.v_coordinate_embeddings_dim
         W = 8 * dim + F_
-        if W != 2 * F_ or W % 64 or cfg.v_hidden_size != cfg.hidden_size or cfg.visual_target_weights.get("6", 0) > 0:
-            raise NotImplementedError("VL-BERT embedding geometry outside the ctrl config (8*dim must equal v_feature_size)")
+        if W != 2 * F_ or W % 64 or cfg.v_hidden_size != cfg.hidden_size:
+            raise NotImplementedError("VL-BERT embedding geometry outside the reference configs (8*dim must equal v_feature_size)")
+        mvrc = cfg.visual_target_weights.get("6", 0) > 0      # masked regions get a word of their own (embeddings.py:191,262-263)
+        nword = 3 if mvrc else 2
         f, dev = self.fwd.ops, self.dev
         i64 = dict(dtype=torch.int64, device=dev)
         nodrop = L.dropout_cfg(None, 0, 0.0)
@@ -699,9 +703,9 @@ class StepEngine:
         self.bufs["vl_row2b"] = row2b = (torch.arange(st_t.M, device=dev, dtype=torch.int32) // T).contiguous()
         self.bufs["vl_cntB"] = cntB = torch.tensor([B], device=dev, dtype=torch.int32)
         self.bufs["vl_cntMt"] = cntMt = torch.tensor([st_t.M], device=dev, dtype=torch.int32)
-        vtab = self.buf("vl_vtab", (2, H), torch.float32)
-        dvtab = self.buf("vl_dvtab", (2, H), torch.float32)
-        self._vlbert = dict(pre=pre, tpos=tpos, opos=opos, vtab=vtab, T=T, K=K)
+        vtab = self.buf("vl_vtab", (nword, H), torch.float32)       # rows: object word, END word (last region), masked-region word
+        dvtab = self.buf("vl_dvtab", (nword, H), torch.float32)
+        self._vlbert = dict(pre=pre, tpos=tpos, opos=opos, vtab=vtab, T=T, K=K, mvrc=mvrc)
         # ---- forward
         x4 = self.buf("vl_x4096", (st_v.M, W))
         zflag = self.buf("vl_zero_flag", (st_v.M,), torch.int32)
@@ -710,6 +714,10 @@ class StepEngine:
         self.patch("image_loc", g, "p", 0)
         self.patch("image_feat", g, "p", 1)
         f.append((L.OP_GENERIC, 0, 0, 0, g, None, None))
+        word_ids = is_last
+        if mvrc:
+            word_ids = self.buf("vl_word_ids", (st_v.M,), torch.int64)
+            f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_VLBERT_OBJ_IDS, p=(zflag, word_ids), n=(st_v.M, K)), None, None))
         final = self.buf("vl_final", (st_v.M, H))
         wds = pre + "obj_downsample.1"
         self.gemm(f, L.NT, L.EPI_RELU, [self.prob(x4, self.W(wds + ".weight"), final, st_v.M, H, W, W, W, H, bias=self.Pm(wds + ".bias"))])
@@ -719,8 +727,8 @@ class StepEngine:
         f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(final, None, pre + "visual_ln_object.weight", pre + "visual_ln_object.bias", obj_vis, None, so[0], so[1], st_v.M, nodrop), None, None))
         vz = self.buf("emb_v_z", (st_v.M, H))
         ptab, ttab = pre + "position_embeddings.weight", pre + "token_type_embeddings.weight"
-        ev = self.k(L.EmbedArgs(_addr(is_last), _addr(twos), _addr(opos), _addr(vtab), _addr(self.Pm(ptab)), _addr(self.Pm(ttab)), _addr(obj_vis), _addr(vz),
-                                st_v.M, K, H, 2, cfg.max_position_embeddings, cfg.type_vocab_size))
+        ev = self.k(L.EmbedArgs(_addr(word_ids), _addr(twos), _addr(opos), _addr(vtab), _addr(self.Pm(ptab)), _addr(self.Pm(ttab)), _addr(obj_vis), _addr(vz),
+                                st_v.M, K, H, nword, cfg.max_position_embeddings, cfg.type_vocab_size))
         f.append((L.OP_EMBED_FWD, 0, 0, 0, ev, None, None))
         flast = self.buf("vl_final_last", (B, H))
         f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_GATHER, p=(final, last_rows, cntB, flast), n=(H, B)), None, None))
@@ -762,11 +770,13 @@ class StepEngine:
         b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dtv, flast, so[2], so[3], pre + "visual_ln_text.weight", pre + "visual_ln_text.bias", dflast, None, B, nodrop), None, None))
         # vision tokens: (object | END) embedding, position, type 2, then LN_obj
         b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MEMSET, p=(dvtab,), n=(dvtab.numel() * 4, 0)), None, None))
-        evb = self.k(L.EmbedBwdArgs(_addr(dzv), _addr(is_last), _addr(twos), _addr(opos), _addr(dvtab), _addr(self.G(ptab)), _addr(self.G(ttab)),
-                                    st_v.M, K, H, cfg.type_vocab_size, 2, cfg.max_position_embeddings))
+        evb = self.k(L.EmbedBwdArgs(_addr(dzv), _addr(word_ids), _addr(twos), _addr(opos), _addr(dvtab), _addr(self.G(ptab)), _addr(self.G(ttab)),
+                                    st_v.M, K, H, cfg.type_vocab_size, nword, cfg.max_position_embeddings))
         b.append((L.OP_EMBED_BWD, 0, 0, 0, evb, None, None))
         b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_COPY, p=(self.G(pre + "object_linguistic_embeddings.weight"), dvtab[0]), n=(H * 4,)), None, None))
         b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_COPY, p=(self.G(pre + "end_embedding.weight"), dvtab[1]), n=(H * 4,)), None, None))
+        if mvrc:
+            b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_COPY, p=(self.G(pre + "object_mask_word_embedding.weight"), dvtab[2]), n=(H * 4,)), None, None))
         dfinal = self.tmp("dd1", (st_v.M, H))
         b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dzv, final, so[0], so[1], pre + "visual_ln_object.weight", pre + "visual_ln_object.bias", dfinal, None, st_v.M, nodrop), None, None))
         b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SCATTER_ADD, p=(dflast, last_rows, cntB, dfinal), n=(H, B)), None, None))
@@ -1029,20 +1039,36 @@ class StepEngine:
         cfg, B, H, T, Rv, R = self.cfg, self.B, self.H, self.T, self.Rv, self.R
         f = self.fwd.ops
         st_t, st_v = self.st
-        P = cfg.pooler_size
-        if P != cfg.v_pooler_size or P % 64:
+        fm = cfg.fusion_method
+        has_itm = fm in ("mul", "sum", "text")         # encoders.py:744-747: no ITM head for "none" / "vl-bert_vqa"
+        P = cfg.pooler_size if has_itm else 0
+        if has_itm and ((fm != "text" and P != cfg.v_pooler_size) or P % 64):
             raise NotImplementedError("pooler sizes must match and be multiples of 64")
+        if fm == "vl-bert_vqa":                        # the VQA text pooler exists but feeds nothing in pre-training (its .grad stays None)
+            self.unused_params |= {"bert.t_pooler.dense.weight", "bert.t_pooler.dense.bias"}
         V, Vp = cfg.vocab_size, _round_up(cfg.vocab_size, 64)
-        Cn, Cp = 1601, _round_up(1601, 64)
+        targets = [(ix, float(w)) for ix, w in cfg.visual_target_weights.items() if w > 0]
+        if not targets:
+            raise NotImplementedError("no visual target with a positive weight")
+        if {ix for ix, _ in targets} & {"1", "2", "5"} and cfg.add_global_imgfeat is not None:
+            raise NotImplementedError("the feature-regression targets compare [B, R, 2048] predictions with the [B, R+1, 2048] input "
+                                      "when a global feature is added (losses.py:28,41,108 fail on the shapes)")
         x_t, x_v = self.x
         self.sums = self.buf("loss_sums", (4,), torch.float32)
         self.losses = self.buf("losses", (3,), torch.float32)
         self.gout = self.buf("gout", (3,), torch.float32)
         f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MEMSET, p=(self.sums,), n=(16, 0)), None, None))
         # ---- ITM: poolers, fusion, classifier
-        pt, pv = self.buf("pooled_t", (B, P)), self.buf("pooled_v", (B, P))
-        self.gemm(f, L.NT, L.EPI_RELU, [self.prob(x_t, self.W("bert.t_pooler.dense.weight"), pt, B, P, H, T * H, H, P, bias=self.Pm("bert.t_pooler.dense.bias")),
-                                        self.prob(x_v, self.W("bert.v_pooler.dense.weight"), pv, B, P, H, Rv * H, H, P, bias=self.Pm("bert.v_pooler.dense.bias"))])
+        pt = pv = None
+        if has_itm:
+            pt = self.buf("pooled_t", (B, P))
+            pools = [self.prob(x_t, self.W("bert.t_pooler.dense.weight"), pt, B, P, H, T * H, H, P, bias=self.Pm("bert.t_pooler.dense.bias"))]
+            if fm != "text":
+                pv = self.buf("pooled_v", (B, P))
+                pools.append(self.prob(x_v, self.W("bert.v_pooler.dense.weight"), pv, B, P, H, Rv * H, H, P, bias=self.Pm("bert.v_pooler.dense.bias")))
+            self.gemm(f, L.NT, L.EPI_RELU, pools)
+        elif fm == "vl-bert_vqa":
+            pt = self._vqa_text_pooler(f, x_t)[0]               # BertModel's fourth output; nothing in the pre-training loss reads it
         # ---- masked LM on labelled rows
         n_t, n_v = self.buf("n_t", (1,), torch.int32), self.buf("n_v", (1,), torch.int32)
         rows_t, pos_t = self.buf("rows_t", (st_t.M,), torch.int32), self.buf("pos_t", (st_t.M,), torch.int32)
@@ -1084,26 +1110,58 @@ class StepEngine:
             f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(hv, None, ci + "transform.LayerNorm.weight", ci + "transform.LayerNorm.bias", hn_v, None, im_mean, im_rstd, Mr, nodrop, dyn=n_v), None, None))
         else:
             hn_v = hv
-        logits_v = self.buf("img_logits", (Mr, Cp), torch.float32)
-        self.gemm(f, L.NT, L.EPI_F32, [self.prob(hn_v, self.W(ci + "decoder_dict.0.weight"), logits_v, Mr, Cn, H, H, H, Cp, bias=self.Pm(ci + "decoder_dict.0.bias"), dyn=n_v, n_store=Cp)])
-        lse_v, tsum_v = self.buf("img_lse", (Mr,), torch.float32), self.buf("img_tsum", (Mr,), torch.float32)
-        kw = float(cfg.visual_target_weights["0"])
-        ka = self.k(L.KlArgs(_addr(logits_v), None, _addr(pos_v), _addr(n_v), _addr(lse_v), _addr(tsum_v), _addr(self.sums[1:2]), kw, Cn, Cp, Mr))
-        self.patch("image_cls", ka, "target")
-        f.append((L.OP_KL_FWD, 0, 0, 0, ka, None, None))
+        # one decoder + loss per configured visual target (encoders.py:718-737,1079-1087; losses.py); all of them add their WEIGHTED row
+        # losses to sums[1], the image loss is sums[1] / max(#masked regions, 1)
+        vis = []                                                # (ix, Cn, Cp, forward-args struct, is_kl)
+        for ix, w in targets:
+            Cn = VIS_TARGET_WIDTH[ix]
+            Cp = _round_up(Cn, 64)
+            tag = "img" if ix == "0" else "img%s" % ix
+            logits_v = self.buf(tag + "_logits", (Mr, Cp), torch.float32)
+            wdec = ci + "decoder_dict.%s." % ix
+            self.gemm(f, L.NT, L.EPI_F32, [self.prob(hn_v, self.W(wdec + "weight"), logits_v, Mr, Cn, H, H, H, Cp, bias=self.Pm(wdec + "bias"), dyn=n_v, n_store=Cp)])
+            lse_v = self.buf(tag + "_lse", (Mr,), torch.float32)
+            if ix == "0":
+                tsum_v = self.buf("img_tsum", (Mr,), torch.float32)
+                la = self.k(L.KlArgs(_addr(logits_v), None, _addr(pos_v), _addr(n_v), _addr(lse_v), _addr(tsum_v), _addr(self.sums[1:2]), w, Cn, Cp, Mr))
+                self.patch("image_cls", la, "target")
+                f.append((L.OP_KL_FWD, 0, 0, 0, la, None, None))
+            else:
+                kind = {"1": L.VIS_MSE, "2": L.VIS_NCE, "3": L.VIS_XENT, "4": L.VIS_XENT, "5": L.VIS_HUBER, "6": L.VIS_XENT}[ix]
+                la = L.VisLossArgs(_addr(logits_v), None, None, None, _addr(pos_v), _addr(n_v), None, _addr(lse_v), None, _addr(self.sums[1:2]), w, Cn, Cp, Mr, kind, 0)
+                self.k(la)
+                if kind in (L.VIS_MSE, L.VIS_HUBER, L.VIS_NCE):
+                    self.patch("image_feat", la, "target")
+                if kind == L.VIS_XENT:
+                    self.patch("attr_labels" if ix == "4" else "obj_labels", la, "labels")
+                    if ix in ("3", "4"):
+                        self.patch("attr_confs" if ix == "4" else "obj_confs", la, "conf")
+                if kind == L.VIS_NCE:
+                    nneg = L.NCE_ACROSS + L.NCE_INSIDE
+                    neg = self.buf("img_nce_neg", (B * R * nneg,), torch.int32)
+                    aux = self.buf("img_nce_scores", (Mr, L.NCE_MAX_SAMPLES), torch.float32)
+                    la.neg_index, la.aux, la.n_neg = _addr(neg), _addr(aux), nneg
+                    self.nce_site = self.site                    # the negatives' counter-based stream (drawn in eval mode too, as the reference does)
+                    self.site += 1
+                    rng = L.rng_cfg(self.seed.data_ptr(), self.nce_site)
+                    f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_NCE_NEG, p=(neg,), n=(B, R), drop=rng), None, None))
+                f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_VIS_LOSS_FWD, p=(la,)), None, None))
+            vis.append((ix, Cn, Cp, la, tag))
         f.append((L.OP_SIDE_END, 11, 0, 0, None, None, None))
         # ---- ITM head (its dropout site is the last one of the forward pass)
-        pooled = self.buf("pooled", (B, P))
-        pdrop = self.drop(0.1)
-        f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_POOL_FWD, p=(pt, pv, pooled), n=(B, P), drop=pdrop), None, None))
-        itm = self.buf("itm_logits", (B, 64), torch.float32)
-        self.gemm(f, L.NT, L.EPI_F32, [self.prob(pooled, self.W("cls.bi_seq_relationship.weight"), itm, B, 2, P, P, P, 64, bias=self.Pm("cls.bi_seq_relationship.bias"), n_store=64)])
-        lse_i = self.buf("itm_lse", (B,), torch.float32)
-        xi = self.k(L.XentArgs(_addr(itm), None, None, None, _addr(lse_i), _addr(self.sums[2:3]), 2, 64, B))
-        self.patch("next_sentence_label", xi, "labels")
-        f.append((L.OP_XENT_FWD, 0, 0, 0, xi, None, None))
+        fuse = {"mul": L.FUSE_MUL, "sum": L.FUSE_SUM, "text": L.FUSE_TEXT}.get(fm)
+        pdrop = self.drop(0.1)                                   # the reference's nn.Dropout(0.1) sits in every variant of the heads
+        if has_itm:
+            pooled = self.buf("pooled", (B, P))
+            f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_POOL_FWD, p=(pt, pv, pooled), n=(B, P, 0, fuse), drop=pdrop), None, None))
+            itm = self.buf("itm_logits", (B, 64), torch.float32)
+            self.gemm(f, L.NT, L.EPI_F32, [self.prob(pooled, self.W("cls.bi_seq_relationship.weight"), itm, B, 2, P, P, P, 64, bias=self.Pm("cls.bi_seq_relationship.bias"), n_store=64)])
+            lse_i = self.buf("itm_lse", (B,), torch.float32)
+            xi = self.k(L.XentArgs(_addr(itm), None, None, None, _addr(lse_i), _addr(self.sums[2:3]), 2, 64, B))
+            self.patch("next_sentence_label", xi, "labels")
+            f.append((L.OP_XENT_FWD, 0, 0, 0, xi, None, None))
         f.append((L.OP_WAIT_SIDE, 11, 0, 0, None, None, None))
-        f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_LOSS_FINAL, p=(self.sums, n_t, n_v, self.losses), n=(B,), f=(kw,)), None, None))
+        f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_LOSS_FINAL, p=(self.sums, n_t, n_v, self.losses), n=(B,), f=(1.0,)), None, None))
         self.taps.update(seq_t=x_t, seq_v=x_v, pooled_t=pt, pooled_v=pv)
 
         # ================= backward of the heads: produces dX[0], dX[1] (buffer 'a').  Three independent chains of small launches:
@@ -1117,12 +1175,19 @@ class StepEngine:
             b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MEMSET, p=(dxh[m],), n=(dxh[m].numel() * 2, 0)), None, None))
         # ---- region chain (side stream)
         b.append((L.OP_SIDE_BEGIN, 0, 0, 0, None, None, None))
-        dlog_v = self.buf("img_dlogits", (Mr, Cp))
-        b.append((L.OP_KL_BWD, Cp, 0, 0, ka, dlog_v, self.gout[1:2]))
         dhn_v = self.tmp("head_v_d1", (Mr, H))
-        wdec = ci + "decoder_dict.0."
-        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dlog_v, self.W(wdec + "weight"), dhn_v, Mr, H, Cn, Cp, H, H, dyn=n_v)])
-        self.gemm(b, L.TN, L.EPI_F32, [self.prob(dlog_v, hn_v, self.G(wdec + "weight"), Cn, H, Mr, Cp, H, H, bias_grad=self.G(wdec + "bias"), dyn=n_v)])
+        for j, (ix, Cn, Cp, la, tag) in enumerate(vis):
+            dlog_v = self.buf(tag + "_dlogits", (Mr, Cp))
+            if ix == "0":
+                b.append((L.OP_KL_BWD, Cp, 0, 0, la, dlog_v, self.gout[1:2]))
+            else:
+                b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_VIS_LOSS_BWD, p=(la, dlog_v, self.gout[1:2]), n=(Cp,)), None, None))
+            wdec = ci + "decoder_dict.%s." % ix
+            if j == 0:
+                self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dlog_v, self.W(wdec + "weight"), dhn_v, Mr, H, Cn, Cp, H, H, dyn=n_v)])
+            else:                                               # the decoders share the transformed hidden state: their input gradients add up
+                self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dlog_v, self.W(wdec + "weight"), dhn_v, Mr, H, Cn, Cp, H, H, dyn=n_v, R=dhn_v, ldr=H)])
+            self.gemm(b, L.TN, L.EPI_F32, [self.prob(dlog_v, hn_v, self.G(wdec + "weight"), Cn, H, Mr, Cp, H, H, bias_grad=self.G(wdec + "bias"), dyn=n_v)])
         if cfg.image_head_ln:
             dhv = self.tmp("head_v_d2", (Mr, H))
             b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dhn_v, hv, im_mean, im_rstd, ci + "transform.LayerNorm.weight", ci + "transform.LayerNorm.bias", dhv, None, Mr, nodrop, dyn=n_v, own_partial=True), None, None))
@@ -1166,15 +1231,19 @@ class StepEngine:
         self.gemm(wg, L.TN, L.EPI_F32, [self.prob(du_t, hx_t, self.G(c + "transform.dense.weight"), H, H, st_t.M, H, H, H, bias_grad=self.G(c + "transform.dense.bias"), dyn=n_t)])
         b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SCATTER_ADD, p=(dhx_t, rows_t, n_t, dxh[0]), n=(H, st_t.M)), None, None))
         # ---- ITM chain
-        dlog_i = self.buf("itm_dlogits", (B, 64))
-        b.append((L.OP_XENT_BWD, 64, 0, 0, xi, dlog_i, self.gout[2:3]))
-        dpooled = self.buf("d_pooled", (B, P))
-        wi = "cls.bi_seq_relationship."
-        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dlog_i, self.W(wi + "weight"), dpooled, B, P, 2, 64, P, P)])
-        self.gemm(wg, L.TN, L.EPI_F32, [self.prob(dlog_i, pooled, self.G(wi + "weight"), 2, P, B, 64, P, P, bias_grad=self.G(wi + "bias"))])
-        dyt, dyv = self.buf("d_pool_t", (B, P)), self.buf("d_pool_v", (B, P))
-        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_POOL_BWD, p=(dpooled, pt, pv, dyt, dyv), n=(B, P, P), drop=pdrop), None, None))
-        for m, (dy_, xm, Lm, pre) in enumerate(((dyt, x_t, T, "bert.t_pooler.dense."), (dyv, x_v, Rv, "bert.v_pooler.dense."))):
+        poolers = []
+        if has_itm:
+            dlog_i = self.buf("itm_dlogits", (B, 64))
+            b.append((L.OP_XENT_BWD, 64, 0, 0, xi, dlog_i, self.gout[2:3]))
+            dpooled = self.buf("d_pooled", (B, P))
+            wi = "cls.bi_seq_relationship."
+            self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dlog_i, self.W(wi + "weight"), dpooled, B, P, 2, 64, P, P)])
+            self.gemm(wg, L.TN, L.EPI_F32, [self.prob(dlog_i, pooled, self.G(wi + "weight"), 2, P, B, 64, P, P, bias_grad=self.G(wi + "bias"))])
+            dyt = self.buf("d_pool_t", (B, P))
+            dyv = self.buf("d_pool_v", (B, P)) if pv is not None else None
+            b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_POOL_BWD, p=(dpooled, pt, pv, dyt, dyv), n=(B, P, P, fuse), drop=pdrop), None, None))
+            poolers = [(0, dyt, x_t, T, "bert.t_pooler.dense.")] + ([(1, dyv, x_v, Rv, "bert.v_pooler.dense.")] if pv is not None else [])
+        for m, dy_, xm, Lm, pre in poolers:
             # rows b * L: the first token of every sample -- disjoint from the labelled rows the region chain scatters into
             self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dy_, self.W(pre + "weight"), dxh[m], B, H, P, P, H, Lm * H, R=dxh[m], ldr=Lm * H)])
             self.gemm(wg, L.TN, L.EPI_F32, [self.prob(dy_, xm, self.G(pre + "weight"), P, H, B, P, Lm * H, H, bias_grad=self.G(pre + "bias"))])
@@ -1186,18 +1255,45 @@ class StepEngine:
         self._head_wgrad_event = 12
         return b
 
+    def _vqa_text_pooler(self, f, x_t):
+        """VLBertTextPooler (volta/encoders.py:610-623): ReLU(dense(hidden state of the token two places before the caption's end)).
+        -> (pooled [B, P], gathered rows [B, H], row index [B], count)."""
+        cfg, B, H, T = self.cfg, self.B, self.H, self.T
+        P = cfg.pooler_size
+        if P % 64:
+            raise NotImplementedError("pooler size must be a multiple of 64")
+        rows, cnt = self.buf("vqa_rows", (B,), torch.int32), self.buf("vqa_cnt", (1,), torch.int32)
+        g = self.generic(L.FN_TEXT_END_ROWS, p=(None, rows, cnt), n=(B, T))
+        self.patch("input_ids", g, "p", 0)
+        f.append((L.OP_GENERIC, 0, 0, 0, g, None, None))
+        xg = self.buf("vqa_x", (B, H))
+        f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_GATHER, p=(x_t, rows, cnt, xg), n=(H, B)), None, None))
+        pt = self.buf("pooled_t", (B, P))
+        self.gemm(f, L.NT, L.EPI_RELU, [self.prob(xg, self.W("bert.t_pooler.dense.weight"), pt, B, P, H, H, H, P, bias=self.Pm("bert.t_pooler.dense.bias"))])
+        return pt, xg, rows, cnt
+
     def _heads_tasks(self):
-        """Poolers only (volta/encoders.py:1004-1011): outputs seq_t, seq_v, pooled_t, pooled_v; the backward is seeded by
-        their upstream gradients, which the host writes (bf16) into `d_seq[m]` (= the dX buffers) and `d_pool_*`."""
+        """Poolers only (volta/encoders.py:1004-1011): outputs seq_t, seq_v, pooled_t, pooled_v (None where the fusion method has no
+        such pooler, :936-947); the backward is seeded by their upstream gradients, which the host writes (bf16) into `d_seq[m]`
+        (= the dX buffers) and `d_pool[m]`."""
         cfg, B, H, T, Rv = self.cfg, self.B, self.H, self.T, self.Rv
         f = self.fwd.ops
+        fm = cfg.fusion_method
         P = cfg.pooler_size
-        if P != cfg.v_pooler_size or P % 64:
+        if fm != "none" and ((fm in ("mul", "sum") and P != cfg.v_pooler_size) or P % 64):
             raise NotImplementedError("pooler sizes must match and be multiples of 64")
         x_t, x_v = self.x
-        pt, pv = self.buf("pooled_t", (B, P)), self.buf("pooled_v", (B, P))
-        self.gemm(f, L.NT, L.EPI_RELU, [self.prob(x_t, self.W("bert.t_pooler.dense.weight"), pt, B, P, H, T * H, H, P, bias=self.Pm("bert.t_pooler.dense.bias")),
-                                        self.prob(x_v, self.W("bert.v_pooler.dense.weight"), pv, B, P, H, Rv * H, H, P, bias=self.Pm("bert.v_pooler.dense.bias"))])
+        pt = pv = None
+        vqa = None
+        if fm == "vl-bert_vqa":
+            pt, xg, rows, cnt = vqa = self._vqa_text_pooler(f, x_t)
+        elif fm != "none":
+            pt = self.buf("pooled_t", (B, P))
+            pools = [self.prob(x_t, self.W("bert.t_pooler.dense.weight"), pt, B, P, H, T * H, H, P, bias=self.Pm("bert.t_pooler.dense.bias"))]
+            if fm != "text":
+                pv = self.buf("pooled_v", (B, P))
+                pools.append(self.prob(x_v, self.W("bert.v_pooler.dense.weight"), pv, B, P, H, Rv * H, H, P, bias=self.Pm("bert.v_pooler.dense.bias")))
+            self.gemm(f, L.NT, L.EPI_RELU, pools)
         self.taps.update(seq_t=x_t, seq_v=x_v, pooled_t=pt, pooled_v=pv)
         # The word-embedding gradient is accumulated with atomics by the embedding backward; in the pre-training model the LM
         # decoder's weight gradient (same tied tensor) is what initialises it, here nothing else writes it: zero it per step.
@@ -1207,12 +1303,20 @@ class StepEngine:
         b = []
         dxh = [self._dx(m, self.level[m] % 2) for m in range(2)]
         self.d_seq = dxh                                   # host copies d(seq_t), d(seq_v) here before the backward list runs
-        self.d_pool = [self.buf("d_pool_t", (B, P)), self.buf("d_pool_v", (B, P))]
+        self.d_pool = [self.buf("d_pool_t", (B, P)) if pt is not None else None, self.buf("d_pool_v", (B, P)) if pv is not None else None]
         for m, (xm, Lm, pre, py) in enumerate(((x_t, T, "bert.t_pooler.dense.", pt), (x_v, Rv, "bert.v_pooler.dense.", pv))):
+            if py is None:
+                continue
             dy_ = self.buf("d_pool_pre%d" % m, (B, P))
             b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_RELU_BWD, p=(self.d_pool[m], py, dy_), n=(B * P,)), None, None))
-            self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dy_, self.W(pre + "weight"), dxh[m], B, H, P, P, H, Lm * H, R=dxh[m], ldr=Lm * H)])
-            self.gemm(b, L.TN, L.EPI_F32, [self.prob(dy_, xm, self.G(pre + "weight"), P, H, B, P, Lm * H, H, bias_grad=self.G(pre + "bias"))])
+            if vqa is not None:                            # the pooled token differs per caption: gathered rows in, scatter-add out
+                dxg = self.buf("vqa_dx", (B, H))
+                self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dy_, self.W(pre + "weight"), dxg, B, H, P, P, H, H)])
+                b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SCATTER_ADD, p=(dxg, rows, cnt, dxh[0]), n=(H, B)), None, None))
+                self.gemm(b, L.TN, L.EPI_F32, [self.prob(dy_, xg, self.G(pre + "weight"), P, H, B, P, H, H, bias_grad=self.G(pre + "bias"))])
+            else:
+                self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dy_, self.W(pre + "weight"), dxh[m], B, H, P, P, H, Lm * H, R=dxh[m], ldr=Lm * H)])
+                self.gemm(b, L.TN, L.EPI_F32, [self.prob(dy_, xm, self.G(pre + "weight"), P, H, B, P, Lm * H, H, bias_grad=self.G(pre + "bias"))])
         return b
 
     # ---------------------------------------------------------------- run
@@ -1278,7 +1382,7 @@ class StepEngine:
                     getattr(struct, field)[index] = addr
 
     def prepare_step(self, seed):
-        if self.train:
+        if self.train or getattr(self, "nce_site", None) is not None:      # nce_2048 draws its negatives in eval mode too
             check(L.lib.vk_set_seed(ptr(self.seed), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), L.stream_ptr()))
         vl = getattr(self, "_vlbert", None)
         if vl is not None:
@@ -1307,6 +1411,8 @@ def _vlbert_positions(self, vl):
     pre = vl["pre"]
     vl["vtab"][0].copy_(self.Pm(pre + "object_linguistic_embeddings.weight")[0])
     vl["vtab"][1].copy_(self.Pm(pre + "end_embedding.weight")[0])
+    if vl.get("mvrc"):
+        vl["vtab"][2].copy_(self.Pm(pre + "object_mask_word_embedding.weight")[0])
 
 
 StepEngine._vlbert_positions = _vlbert_positions

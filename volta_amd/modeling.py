@@ -169,13 +169,17 @@ class BertModel(PreTrainedModel):
         else:
             raise ValueError("unknown image_embeddings %r" % kind)
         self.encoder = BertEncoder(config)
-        self.fusion_method = config.fusion_method
-        if config.fusion_method != "mul":
-            raise NotImplementedError("fusion_method %r: only 'mul' (all ctrl_* configs) is on the hot path" % config.fusion_method)
-        assert config.pooler_size == config.v_pooler_size, "pooler_size != v_pooler_size"
-        self.t_pooler, self.v_pooler = M.Holder(), M.Holder()
-        self.t_pooler.add_module("dense", M.LinearParams(config.hidden_size, config.pooler_size))
-        self.v_pooler.add_module("dense", M.LinearParams(config.v_hidden_size, config.v_pooler_size))
+        self.fusion_method = fm = config.fusion_method
+        if fm not in ("sum", "mul", "text", "vl-bert_vqa", "none"):
+            raise ValueError("Invalid fusion method: %s" % fm)
+        # encoders.py:936-947: "none" has no poolers, "text" / "vl-bert_vqa" (VLBertTextPooler, :610-623) no vision pooler
+        if fm != "none":
+            self.t_pooler = M.Holder()
+            self.t_pooler.add_module("dense", M.LinearParams(config.hidden_size, config.pooler_size))
+        if fm in ("sum", "mul"):
+            assert config.pooler_size == config.v_pooler_size, "pooler_size != v_pooler_size"
+            self.v_pooler = M.Holder()
+            self.v_pooler.add_module("dense", M.LinearParams(config.v_hidden_size, config.v_pooler_size))
         M.init_bert_(self, config.initializer_range)
         M.special_init_embeddings_(self.embeddings, kind, config)
 
@@ -204,7 +208,8 @@ class BertPreTrainingHeads(M.Holder):
         pred.add_module("decoder", dec)
         pred.bias = nn.Parameter(torch.zeros(bert_model_embedding_weights.size(0)))
         self.add_module("predictions", pred)
-        self.add_module("bi_seq_relationship", M.LinearParams(config.pooler_size, 2))
+        if config.fusion_method not in ("none", "vl-bert_vqa"):            # encoders.py:744-747
+            self.add_module("bi_seq_relationship", M.LinearParams(config.pooler_size, 2))
         img, itr = M.Holder(), M.Holder()
         itr.add_module("dense", M.LinearParams(Hv, Hv))
         if config.image_head_ln:
@@ -304,7 +309,8 @@ class BertForVLPreTraining(PreTrainedModel):
         self.__dict__["_fp8"] = dtype == "fp8"
 
     def _prep_inputs(self, input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask,
-                     masked_lm_labels, image_label, image_cls, next_sentence_label):
+                     masked_lm_labels, image_label, image_cls, next_sentence_label, obj_labels=None, obj_confs=None,
+                     attr_labels=None, attr_confs=None):
         dev = next(self.parameters()).device
         B, T = input_ids.shape
         Rv = image_feat.shape[1]
@@ -325,10 +331,27 @@ class BertForVLPreTraining(PreTrainedModel):
         if masked_lm_labels is not None:
             t["masked_lm_labels"] = masked_lm_labels.to(**i64).contiguous()
             t["image_label"] = image_label.to(**i64).contiguous()
-            t["image_cls"] = image_cls.to(**f32).contiguous()
-            t["next_sentence_label"] = next_sentence_label.to(**i64).contiguous()
             assert t["masked_lm_labels"].shape == (B, T) and t["image_label"].shape == (B, R)
-            assert t["image_cls"].shape == (B, R, 1601) and t["next_sentence_label"].numel() == B
+            # what each configured visual target reads (volta/losses.py); the reference silently drops a target whose inputs are
+            # missing -- here that is an error, the plan was compiled for the configured targets
+            need = set()
+            for ix, w in self.config.visual_target_weights.items():
+                if w > 0:
+                    need |= {"0": {"image_cls"}, "3": {"obj_labels", "obj_confs"}, "4": {"attr_labels", "attr_confs"}, "6": {"obj_labels"}}.get(ix, set())
+            given = dict(image_cls=image_cls, obj_labels=obj_labels, obj_confs=obj_confs, attr_labels=attr_labels, attr_confs=attr_confs)
+            for name in sorted(need):
+                if given[name] is None:
+                    raise ValueError("visual target weights %r need `%s`" % (self.config.visual_target_weights, name))
+                x = given[name].to(**(i64 if name.endswith("labels") else f32)).contiguous()
+                assert x.shape[:2] == (B, R), "%s must be [B, regions%s]" % (name, ", 1601" if name == "image_cls" else "")
+                t[name] = x
+            if "image_cls" in t:
+                assert t["image_cls"].shape == (B, R, 1601)
+            if self.bert.fusion_method in ("mul", "sum", "text"):
+                if next_sentence_label is None:
+                    raise ValueError("fusion method %r has an ITM head: next_sentence_label is required" % self.bert.fusion_method)
+                t["next_sentence_label"] = next_sentence_label.to(**i64).contiguous()
+                assert t["next_sentence_label"].numel() == B
             # ids / labels are range-clamped inside the kernels: no host synchronisation on the hot path
         return t, B, T, Rv
 
@@ -362,7 +385,9 @@ class BertForVLPreTraining(PreTrainedModel):
         skip = getattr(self, "_torch_param_prefixes", ())
         # frozen parameters (requires_grad False: volta/train_utils.py:250-255) get no .grad, as under autograd; the
         # optimizer and clip_grad_norm_ then leave their arena chunks alone
-        pairs = [((n, p), g) for (n, p), g in zip(arena.param_list(), arena.grad_views()) if p.requires_grad and not (skip and n.startswith(skip))]
+        unused = eng.unused_params          # e.g. the VQA text pooler in pre-training: no launch reads it, .grad stays None
+        pairs = [((n, p), g) for (n, p), g in zip(arena.param_list(), arena.grad_views())
+                 if p.requires_grad and not (skip and n.startswith(skip)) and n not in unused]
         params, gviews = [x[0] for x in pairs], [x[1] for x in pairs]
         n_have = sum(p.grad is not None for _, p in params)
         accumulate = n_have == len(params)
@@ -403,11 +428,12 @@ class BertForVLPreTraining(PreTrainedModel):
                 output_all_attention_masks=False):
         if output_all_attention_masks:
             raise NotImplementedError("attention maps are never materialised by the fused attention kernel")
-        if masked_lm_labels is None or image_label is None or image_cls is None or next_sentence_label is None:
-            raise NotImplementedError("the pre-training step needs masked_lm_labels, image_label, image_cls and "
-                                      "next_sentence_label (the score-returning branch of encoders.py:1113-1114 is not on the hot path)")
+        if masked_lm_labels is None or image_label is None:
+            raise NotImplementedError("the pre-training step needs masked_lm_labels and image_label (the score-returning branch of "
+                                      "encoders.py:1113-1114 is reached only when every loss is zero and is not on the hot path)")
         tensors, B, T, Rv = self._prep_inputs(input_ids, image_feat, image_loc, token_type_ids, attention_mask,
-                                              image_attention_mask, masked_lm_labels, image_label, image_cls, next_sentence_label)
+                                              image_attention_mask, masked_lm_labels, image_label, image_cls, next_sentence_label,
+                                              obj_labels, obj_confs, attr_labels, attr_confs)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             self.materialize()
             anchor = next(p for p in self.parameters() if p.requires_grad)
@@ -422,14 +448,17 @@ class BertForVLPreTraining(PreTrainedModel):
         dev = next(self.parameters()).device
         dummy = dict(masked_lm_labels=torch.full((B, T), -1, dtype=torch.int64, device=dev),
                      image_label=torch.full((B, R), -1, dtype=torch.int64, device=dev),
-                     image_cls=torch.zeros(B, R, 1601, device=dev), next_sentence_label=torch.zeros(B, dtype=torch.int64, device=dev))
+                     image_cls=torch.zeros(B, R, 1601, device=dev), next_sentence_label=torch.zeros(B, dtype=torch.int64, device=dev),
+                     obj_labels=torch.zeros(B, R, dtype=torch.int64, device=dev), obj_confs=torch.zeros(B, R, device=dev),
+                     attr_labels=torch.zeros(B, R, dtype=torch.int64, device=dev), attr_confs=torch.zeros(B, R, device=dev))
         tensors, B, T, Rv = self._prep_inputs(input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask, **dummy)
         with torch.no_grad():
             self._engine_forward(tensors)
         eng = self._last[0]
         H = self.config.hidden_size
+        pt, pv = eng.taps["pooled_t"], eng.taps["pooled_v"]          # None where the fusion method has no such pooler
         return (eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, H).float(),
-                eng.taps["pooled_t"].float(), eng.taps["pooled_v"].float(), ([], []))
+                None if pt is None else pt.float(), None if pv is None else pv.float(), ([], []))
 
 
 # ======================================================================================== downstream tasks
@@ -455,8 +484,11 @@ class _TaskEncode(torch.autograd.Function):
         B, T = tensors["input_ids"].shape
         Rv = tensors["image_feat"].shape[1]
         H = model.config.hidden_size
-        return (eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, H).float(),
-                eng.taps["pooled_t"].float(), eng.taps["pooled_v"].float())
+        seq_t = eng.taps["seq_t"].view(B, T, H).float()
+        # a pooler the fusion method does not have (encoders.py:936-947) leaves an empty, non-differentiable placeholder
+        pooled = [seq_t.new_zeros(0) if eng.taps[k] is None else eng.taps[k].float() for k in ("pooled_t", "pooled_v")]
+        ctx.mark_non_differentiable(*[p for p in pooled if p.numel() == 0])
+        return seq_t, eng.taps["seq_v"].view(B, Rv, H).float(), pooled[0], pooled[1]
 
     @staticmethod
     def backward(ctx, g_seq_t, g_seq_v, g_pt, g_pv):
@@ -464,6 +496,8 @@ class _TaskEncode(torch.autograd.Function):
         eng, _ = model._last
         state = model._backward_begin(eng)
         for dst, g in ((eng.d_seq[0], g_seq_t), (eng.d_seq[1], g_seq_v), (eng.d_pool[0], g_pt), (eng.d_pool[1], g_pv)):
+            if dst is None:
+                continue
             if g is None:
                 dst.zero_()
             else:
@@ -561,8 +595,9 @@ class BertForVLTasks(PreTrainedModel):
             self._engine_forward(tensors)
         eng = self._last[0]
         H = self.config.hidden_size
+        pt, pv = eng.taps["pooled_t"], eng.taps["pooled_v"]          # None where the fusion method has no such pooler
         return (eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, H).float(),
-                eng.taps["pooled_t"].float(), eng.taps["pooled_v"].float(), ([], []))
+                None if pt is None else pt.float(), None if pv is None else pv.float(), ([], []))
 
     def forward(self, input_txt, input_imgs, image_loc, task_id, token_type_ids=None, attention_mask=None,
                 image_attention_mask=None, output_all_encoded_layers=False, output_all_attention_masks=False):
@@ -581,9 +616,15 @@ class BertForVLTasks(PreTrainedModel):
             eng = self._last[0]
             H = self.config.hidden_size
             seq_t, seq_v = eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, H).float()
-            pooled_t, pooled_v = eng.taps["pooled_t"].float(), eng.taps["pooled_v"].float()
-        if self.fusion_method == "mul":
+            pooled_t, pooled_v = [None if eng.taps[k] is None else eng.taps[k].float() for k in ("pooled_t", "pooled_v")]
+        if self.fusion_method == "sum":                          # encoders.py:1184-1195
+            pooled_output = self.dropout(pooled_t + pooled_v)
+        elif self.fusion_method == "mul":
             pooled_output = self.dropout(pooled_t * pooled_v)
+        elif self.fusion_method in ("text", "vl-bert_vqa"):      # vl-bert_vqa: VLBertTextPooler's token (encoders.py:610-623), pooled by the engine
+            pooled_output = self.dropout(pooled_t)
+        elif self.fusion_method == "none":
+            pooled_output = None
         else:
             raise ValueError("Invalid fusion method: %s" % self.fusion_method)
         task_type = self.task_cfg[task_id]["type"]
