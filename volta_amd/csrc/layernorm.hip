@@ -38,7 +38,7 @@ __device__ __forceinline__ void store4(uint16_t* p, const float (&v)[4]) {
 // the launch saves one ramp and fills the chip better than two half-empty grids.
 // (The job's argument block is read from the kernel-argument segment at a workgroup-uniform offset: selecting between
 // two by-value structs through a reference makes hipcc spill both to scratch.)
-template <typename T> struct JobPair { T job[2]; int32_t nb0; };
+template <typename T> struct JobPair { T job[2]; int32_t nb0; int32_t stagger, stagger_mod; };      // stagger: study builds (0 otherwise)
 template <typename T>
 __device__ __forceinline__ T load_job(int which) {
     static_assert(sizeof(T) % 8 == 0 && alignof(T) == 8, "argument blocks are copied in 8-byte words");
@@ -157,9 +157,20 @@ __global__ __launch_bounds__(LN_THREADS) void ln_fwd_kernel(const JobPair<vk_ln_
     }
 }
 
+// `stamps` (study builds; NULL in the shipped library's launches): per workgroup four s_memrealtime readings (100 MHz) -- entry, first
+// row's statistics done (= its operands arrived), last row stored, record written -- into a buffer no other code reads (tools/stamp_ln.py).
 template <int NCH>
-__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const JobPair<vk_ln_bwd_args> jp) {
+__global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const JobPair<vk_ln_bwd_args> jp, unsigned long long* const stamps) {
     __shared__ float red[4][2][NCH * 256];
+    const bool stamping = stamps != nullptr && threadIdx.x == 0;
+#ifdef VK_STUDY
+    if (jp.stagger > 0) {          // experiment: de-phase the workgroups of the single resident round (measured: no gain)
+        const int k = jp.stagger_mod > 1 ? (int)(blockIdx.x % (unsigned)jp.stagger_mod) : 0;
+        const unsigned long long until = __builtin_amdgcn_s_memrealtime() + (unsigned long long)(k * jp.stagger);
+        while (__builtin_amdgcn_s_memrealtime() < until) __builtin_amdgcn_s_sleep(4);
+    }
+#endif
+    if (stamping) stamps[(size_t)blockIdx.x * 4 + 0] = __builtin_amdgcn_s_memrealtime();
     const int nb0 = jp.nb0;
     const bool second = (int)blockIdx.x >= nb0;
     const vk_ln_bwd_args a = load_job<vk_ln_bwd_args>(second);
@@ -242,6 +253,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const JobPair<vk_ln_
         request(it + PRE, rdy[it % PRE], rz[it % PRE]);        // this row's raw registers are free: they fetch the row after next
         s1 = wave_sum(s1) / (float)H;
         s2 = wave_sum(s2) / (float)H;
+        if (stamping && it == 0) stamps[(size_t)blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
         uint16_t* dz = (uint16_t*)a.dz + (size_t)row * H;
         uint16_t* dd = a.dd ? (uint16_t*)a.dd + (size_t)row * H : nullptr;
 #pragma unroll
@@ -262,6 +274,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const JobPair<vk_ln_
             }
         }
     }
+    if (stamping) stamps[(size_t)blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
     // reduce the four waves' column partials, one [2][H] record per workgroup
 #pragma unroll
     for (int j = 0; j < NCH; ++j)
@@ -276,6 +289,7 @@ __global__ __launch_bounds__(LN_THREADS) void ln_bwd_kernel(const JobPair<vk_ln_
         const int which = i / (NCH * 256), c = i - which * NCH * 256;
         if (c < H) out[which * H + c] = red[0][which][c] + red[1][which][c] + red[2][which][c] + red[3][which][c];
     }
+    if (stamping) stamps[(size_t)blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
 // column sums of the per-workgroup partial records: 64 columns x 16 row groups per workgroup
@@ -316,6 +330,7 @@ extern "C" int vk_ln_fwd_pair(const vk_ln_args* a, const vk_ln_args* b, vk_strea
     jp.job[0] = *a;
     jp.job[1] = b ? *b : *a;
     jp.nb0 = nb0;
+    jp.stagger = jp.stagger_mod = 0;
     switch (nch) {
         case 1: hipLaunchKernelGGL(ln_fwd_kernel<1>, grid, block, 0, s, jp); break;
         case 2: hipLaunchKernelGGL(ln_fwd_kernel<2>, grid, block, 0, s, jp); break;
@@ -329,6 +344,16 @@ extern "C" int vk_ln_fwd_pair(const vk_ln_args* a, const vk_ln_args* b, vk_strea
 extern "C" int vk_ln_fwd(const vk_ln_args* a, vk_stream_t stream) { return vk_ln_fwd_pair(a, nullptr, stream); }
 
 extern "C" int vk_ln_bwd_partial_rows(int M) { return (M + vk::LN_BWD_ROWS - 1) / vk::LN_BWD_ROWS; }
+
+#ifdef VK_STUDY
+static unsigned long long* g_ln_stamps = nullptr;          // tools/stamp_ln.py
+static int g_ln_stagger = 0, g_ln_stagger_mod = 0;          // experiment: workgroup i waits (i % mod) * stagger ticks (10 ns) before it starts
+extern "C" void vk_ln_set_stamp_buffer(unsigned long long* p) { g_ln_stamps = p; }
+extern "C" void vk_ln_set_stagger(int ticks, int mod) { g_ln_stagger = ticks; g_ln_stagger_mod = mod; }
+#else
+static constexpr unsigned long long* g_ln_stamps = nullptr;
+static constexpr int g_ln_stagger = 0, g_ln_stagger_mod = 0;
+#endif
 
 static void ln_finalize_launch(const vk_ln_bwd_args* a, hipStream_t s) {
     hipLaunchKernelGGL(vk::ln_bwd_finalize_kernel, dim3((2 * a->H + 63) / 64), dim3(1024), 0, s, a->partial, vk_ln_bwd_partial_rows(a->M), a->H,
@@ -348,11 +373,12 @@ extern "C" int vk_ln_bwd_pair(const vk_ln_bwd_args* a, const vk_ln_bwd_args* b, 
     jp.job[0] = *a;
     jp.job[1] = b ? *b : *a;
     jp.nb0 = nb0;
+    jp.stagger = g_ln_stagger; jp.stagger_mod = g_ln_stagger_mod;
     switch (nch) {
-        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, jp); break;
-        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, jp); break;
-        case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, jp); break;
-        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, jp); break;
+        case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, jp, g_ln_stamps); break;
+        case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, jp, g_ln_stamps); break;
+        case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, jp, g_ln_stamps); break;
+        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, jp, g_ln_stamps); break;
     }
     if (nb0 && !(a->accumulate & 2)) ln_finalize_launch(a, s);
     if (nb1 && !(b->accumulate & 2)) ln_finalize_launch(b, s);
