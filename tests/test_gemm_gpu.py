@@ -154,3 +154,26 @@ def test_gemm_strided_views():
     ref = A.float() @ W.float().t()
     assert (Cv.float() - ref).abs().max().item() < 0.05 * ref.abs().max().item()
     assert torch.all(out[:, :2 * H] == 0)
+
+
+@pytest.mark.parametrize("K", [1, 2, 3, 1601, 3129])
+def test_gemm_nn_ragged_contraction_keeps_the_last_row(K):
+    """dX = dlogits[M, K] . W[K, N] with the logits' leading dimension padded to 64 and the pad written as 0 (the heads' dgrad): every
+    K, odd ones included, must use the last element of the LAST row -- raw buffer loads are range-checked per dword, so a bound that ends
+    inside a dword drops it (K = 1, the one-column region-logit head, lost the whole last row)."""
+    L, ops = _mods()
+    g = torch.Generator(device="cuda").manual_seed(K)
+    M, N = 148, 768
+    ld = (K + 63) // 64 * 64
+    A = torch.zeros(M, ld, device="cuda", dtype=torch.bfloat16)
+    A[:, :K] = rnd((M, K), g)
+    B = rnd((K, N), g)
+    C = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+    p = ops.gemm_problem(A, B, C, L.NN, M, N, K)
+    ops.gemm_grouped(L.NN, L.EPI_BF16, [p])
+    torch.cuda.synchronize()
+    ref = A[:, :K].float() @ B.float()
+    err = (C.float() - ref).abs().max().item()
+    assert err <= 1e-2 * max(ref.abs().max().item(), 1.0), (K, err)
+    last = (C[-1].float() - ref[-1]).abs().max().item()
+    assert last <= 1e-2 * max(ref[-1].abs().max().item(), 1e-3), (K, "last row", last)

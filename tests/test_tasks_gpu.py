@@ -64,7 +64,7 @@ def test_task_heads_forward_backward_parity(cfg_name):
             e = rel(got, want.detach())
         assert e <= 3e-2, (t, e)
         named = dict(model.named_parameters())
-        checked, worst = 0, 0.0
+        checked, worst, bad = 0, 0.0, []
         pooled_only = not TASK_CFG[t]["type"].startswith("V-logit")
         for k, leaf in leaves.items():
             if leaf.grad is None or k not in named or k.endswith("key.bias"):      # d/d(key bias) is identically zero (softmax shift invariance)
@@ -82,8 +82,10 @@ def test_task_heads_forward_backward_parity(cfg_name):
                 tol = max(tol, 0.25 if pooled_only else 0.15)
             e_k = rel(g.float().cpu(), leaf.grad)
             worst = max(worst, e_k)
-            assert e_k <= tol, (t, k, e_k)
+            if e_k > tol:
+                bad.append((k, round(e_k, 4), tol))
             checked += 1
+        assert not bad, (t, bad[:10], len(bad), checked)
         assert checked > 20, checked
         print(cfg_name, t, "prediction %.2e  worst gradient %.2e over %d parameters" % (e, worst, checked))
 

@@ -93,8 +93,8 @@ void gemm_kernel(const KGroup g) {
     if (m0 >= M) return;
 
     // buffer extents: last valid row + valid row length (everything beyond reads as zero)
-    const int a_rows = AT ? K : M, a_cols = AT ? P.lda : K;
-    const int b_rows = BT ? K : P.N, b_cols = BT ? P.ldb : K;
+    const int a_rows = AT ? K : M, a_cols = AT ? P.lda : even_up(K, P.lda);
+    const int b_rows = BT ? K : P.N, b_cols = BT ? P.ldb : even_up(K, P.ldb);
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(P.A, a_rows > 0 ? (uint32_t)(((uint32_t)(a_rows - 1) * P.lda + a_cols) * 2u) : 0u);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(P.B, b_rows > 0 ? (uint32_t)(((uint32_t)(b_rows - 1) * P.ldb + b_cols) * 2u) : 0u);
 

@@ -96,8 +96,8 @@ __global__ __launch_bounds__(512) void gemm256_kernel(const KGroup g) {
     }
     if (m0 >= M) return;
 
-    const int a_rows = AT ? K : M, a_cols = AT ? P.lda : K;
-    const int b_rows = BT ? K : P.N, b_cols = BT ? P.ldb : K;
+    const int a_rows = AT ? K : M, a_cols = AT ? P.lda : even_up(K, P.lda);
+    const int b_rows = BT ? K : P.N, b_cols = BT ? P.ldb : even_up(K, P.ldb);
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(P.A, a_rows > 0 ? (uint32_t)(((uint32_t)(a_rows - 1) * P.lda + a_cols) * 2u) : 0u);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(P.B, b_rows > 0 ? (uint32_t)(((uint32_t)(b_rows - 1) * P.ldb + b_cols) * 2u) : 0u);
 
@@ -293,8 +293,8 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
     }
     if (m0 >= M) return;
 
-    const int a_rows = AT ? K : M, a_cols = AT ? P.lda : K;
-    const int b_rows = BT ? K : P.N, b_cols = BT ? P.ldb : K;
+    const int a_rows = AT ? K : M, a_cols = AT ? P.lda : even_up(K, P.lda);
+    const int b_rows = BT ? K : P.N, b_cols = BT ? P.ldb : even_up(K, P.ldb);
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(P.A, a_rows > 0 ? (uint32_t)(((uint32_t)(a_rows - 1) * P.lda + a_cols) * 2u) : 0u);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(P.B, b_rows > 0 ? (uint32_t)(((uint32_t)(b_rows - 1) * P.ldb + b_cols) * 2u) : 0u);
 
@@ -399,8 +399,8 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int
         const int tm = t / P.tiles_n, tn = t - tm * P.tiles_n;
         m0 = tm * 256; n0 = tn * BN;
         const int M = P.M, K = P.K;
-        const int a_rows = AT ? K : M, a_cols = AT ? P.lda : K;
-        const int b_rows = BT ? K : P.N, b_cols = BT ? P.ldb : K;
+        const int a_rows = AT ? K : M, a_cols = AT ? P.lda : even_up(K, P.lda);
+        const int b_rows = BT ? K : P.N, b_cols = BT ? P.ldb : even_up(K, P.ldb);
         rsA = make_rsrc(P.A, a_rows > 0 ? (uint32_t)(((uint32_t)(a_rows - 1) * P.lda + a_cols) * 2u) : 0u);
         rsB = make_rsrc(P.B, b_rows > 0 ? (uint32_t)(((uint32_t)(b_rows - 1) * P.ldb + b_cols) * 2u) : 0u);
         strip_offsets<AT>(offA, P.lda, m0, 256, tid);

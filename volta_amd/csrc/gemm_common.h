@@ -63,6 +63,12 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // Every global READ of the epilogue (bias, residual / multiplier R, accumulate-into C) is an unconditional
 // bounds-checked buffer load -- absent operands and out-of-range rows / columns read as 0 -- so the compiler can
 // issue them all up front instead of one dependent L2 round trip per element; only the stores are predicated.
+// Extent of a K-contiguous operand row for the buffer bounds: raw buffer loads are range-checked per DWORD, so with an odd K the dword that
+// holds element K-1 of the LAST row would count as out of range and read as zero (found with the one-column region-logit head: K = 1 lost
+// the whole last row).  The row is extended to an even element count inside its leading dimension; the extra element is a pad column, which
+// is zero by the ragged-K contract (lda padded to a multiple of 64, pad written as 0) or meets an out-of-range (zero) row of the other operand.
+__device__ __forceinline__ int even_up(int K, int ld) { const int e = (K + 1) & ~1; return e < ld ? e : ld; }
+
 template <bool AT, int EPI, int TI, int TJ, int REGION = 16384>       // REGION: bytes of the wave-private LDS staging region
 __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][TJ], f32x4 (&accb)[TI], bool do_bias_grad,
                                               int m_base, int n_base, int M, int lane, uint32_t lds_region = 0) {

@@ -362,7 +362,7 @@ static void ln_finalize_launch(const vk_ln_bwd_args* a, hipStream_t s) {
 
 extern "C" int vk_ln_bwd_pair(const vk_ln_bwd_args* a, const vk_ln_bwd_args* b, vk_stream_t stream) {
     using namespace vk;
-    if (ln_check(a->H, 1024, "vk_ln_bwd")) return -1;
+    if (ln_check(a->H, 2048, "vk_ln_bwd")) return -1;
     if (b && (b->H != a->H || a->dyn || b->dyn)) return set_error("vk_ln_bwd_pair: both jobs need the same H and static row counts");
     const int nb0 = a->M > 0 ? vk_ln_bwd_partial_rows(a->M) : 0, nb1 = (b && b->M > 0) ? vk_ln_bwd_partial_rows(b->M) : 0;
     if (nb0 + nb1 == 0) return 0;
@@ -378,7 +378,9 @@ extern "C" int vk_ln_bwd_pair(const vk_ln_bwd_args* a, const vk_ln_bwd_args* b, 
         case 1: hipLaunchKernelGGL(ln_bwd_kernel<1>, grid, block, 0, s, jp, g_ln_stamps); break;
         case 2: hipLaunchKernelGGL(ln_bwd_kernel<2>, grid, block, 0, s, jp, g_ln_stamps); break;
         case 3: hipLaunchKernelGGL(ln_bwd_kernel<3>, grid, block, 0, s, jp, g_ln_stamps); break;
-        default: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, jp, g_ln_stamps); break;
+        case 4: hipLaunchKernelGGL(ln_bwd_kernel<4>, grid, block, 0, s, jp, g_ln_stamps); break;
+        case 5: case 6: hipLaunchKernelGGL(ln_bwd_kernel<6>, grid, block, 0, s, jp, g_ln_stamps); break;      // clf_hidden_size 1536 (task classifiers)
+        default: hipLaunchKernelGGL(ln_bwd_kernel<8>, grid, block, 0, s, jp, g_ln_stamps); break;
     }
     if (nb0 && !(a->accumulate & 2)) ln_finalize_launch(a, s);
     if (nb1 && !(b->accumulate & 2)) ln_finalize_launch(b, s);

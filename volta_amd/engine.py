@@ -215,6 +215,8 @@ def _addr(o):
     if o is None:
         return None
     if isinstance(o, int):
+        if 0 < o < (1 << 16):        # a count or an index handed over where a buffer was meant: never a device address
+            raise ValueError("engine: %d is not a device address" % o)
         return o
     if isinstance(o, torch.Tensor):
         return o.data_ptr()
@@ -233,13 +235,14 @@ class StepEngine:
 
     H8_MUL = 8.0           # static scale of the fp8 copy of the GELU output: |h| <= 56 representable, 2^-9 absolute resolution near 0
 
-    def __init__(self, cfg, arena, B, T, Rv, train, heads="pretrain", fp8=False):
+    def __init__(self, cfg, arena, B, T, Rv, train, heads="pretrain", fp8=False, task=None):
         """fp8: the forward Q|K|V, FFN-up and FFN-down projections of every sub-layer run on the e4m3 MFMA path (csrc/fp8.hip); inputs are
         quantised per row right before the GEMM, weights per output channel whenever they change; the backward stays bf16.
         heads: "pretrain" = the three pre-training heads and losses (BertForVLPreTraining); "tasks" = poolers only, the
         sequence and pooled outputs leave the engine and their gradients enter it (BertForVLTasks)."""
         self.cfg, self.arena, self.B, self.T, self.Rv, self.train = cfg, arena, B, T, Rv, train
         self.heads = heads
+        self.task = task              # heads == "tasks": (task id, its task_cfg entry) -- the classifier built behind the poolers
         self.fp8 = bool(fp8)
         dev = arena.device
         self.dev = dev
@@ -1273,9 +1276,12 @@ class StepEngine:
         return pt, xg, rows, cnt
 
     def _heads_tasks(self):
-        """Poolers only (volta/encoders.py:1004-1011): outputs seq_t, seq_v, pooled_t, pooled_v (None where the fusion method has no
-        such pooler, :936-947); the backward is seeded by their upstream gradients, which the host writes (bf16) into `d_seq[m]`
-        (= the dX buffers) and `d_pool[m]`."""
+        """BertForVLTasks behind the encoder (volta/encoders.py:1117-1206): poolers (:1004-1011; none / text-only / VLBertTextPooler by fusion
+        method, :936-947), the fusion + dropout of the pooled vectors (:1184-1195) and the task's classifier (:1128-1149: SimpleClassifier =
+        Linear -> GELU -> LayerNorm -> Linear (:787-814), plain Linear heads, the one- and two-layer region-logit heads on dropout(seq_v)),
+        forward and backward.  The prediction leaves the engine as fp32 logits (`self.pred`, leading dimension padded to 64); the backward is
+        seeded by d(loss)/d(logits), which the host writes (bf16) into `self.d_pred`.  Without a task (BertModel.forward / encode()) only the
+        poolers are built."""
         cfg, B, H, T, Rv = self.cfg, self.B, self.H, self.T, self.Rv
         f = self.fwd.ops
         fm = cfg.fusion_method
@@ -1283,10 +1289,11 @@ class StepEngine:
         if fm != "none" and ((fm in ("mul", "sum") and P != cfg.v_pooler_size) or P % 64):
             raise NotImplementedError("pooler sizes must match and be multiples of 64")
         x_t, x_v = self.x
+        st_v = self.st[1]
         pt = pv = None
         vqa = None
         if fm == "vl-bert_vqa":
-            pt, xg, rows, cnt = vqa = self._vqa_text_pooler(f, x_t)
+            pt, xg, vqa_rows, vqa_cnt = vqa = self._vqa_text_pooler(f, x_t)
         elif fm != "none":
             pt = self.buf("pooled_t", (B, P))
             pools = [self.prob(x_t, self.W("bert.t_pooler.dense.weight"), pt, B, P, H, T * H, H, P, bias=self.Pm("bert.t_pooler.dense.bias"))]
@@ -1302,21 +1309,110 @@ class StepEngine:
                 self._zero_grad(self.G(nm))
         b = []
         dxh = [self._dx(m, self.level[m] % 2) for m in range(2)]
-        self.d_seq = dxh                                   # host copies d(seq_t), d(seq_v) here before the backward list runs
-        self.d_pool = [self.buf("d_pool_t", (B, P)) if pt is not None else None, self.buf("d_pool_v", (B, P)) if pv is not None else None]
-        for m, (xm, Lm, pre, py) in enumerate(((x_t, T, "bert.t_pooler.dense.", pt), (x_v, Rv, "bert.v_pooler.dense.", pv))):
+        for m in range(2):                                 # the sequence outputs feed nothing but the task head
+            b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MEMSET, p=(dxh[m],), n=(dxh[m].numel() * 2, 0)), None, None))
+        self.pred = self.d_pred = None
+        heads_of_other_tasks = [nm for nm in self.arena.params if nm.startswith("clfs_dict.")]
+        dpool = [None, None]                               # gradients at the poolers' pre-activation outputs
+        if self.task is not None:
+            task_id, tcfg = self.task
+            typ = tcfg["type"]
+            pre = "clfs_dict.%s." % task_id
+            heads_of_other_tasks = [nm for nm in heads_of_other_tasks if not nm.startswith(pre)]
+            nodrop = L.dropout_cfg(None, 0, 0.0)
+
+            def linear_out(x, rows, K, wname, C):
+                """logits = x W^T + b as fp32 [rows, 64 k]; returns (logits, dlogits bf16)."""
+                Cp = _round_up(C, 64)
+                out = self.buf("task_logits", (rows, Cp), torch.float32)
+                self.gemm(f, L.NT, L.EPI_F32, [self.prob(x, self.W(wname + "weight"), out, rows, C, K, K, K, Cp, bias=self.Pm(wname + "bias"), n_store=Cp)])
+                return out, self.buf("task_dlogits", (rows, Cp), zero=True), Cp
+
+            def linear_bwd(dlog, Cp, x, rows, K, wname, C, dx):
+                self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dlog, self.W(wname + "weight"), dx, rows, K, C, Cp, K, K)])
+                self.gemm(b, L.TN, L.EPI_F32, [self.prob(dlog, x, self.G(wname + "weight"), C, K, rows, Cp, K, K, bias_grad=self.G(wname + "bias"))])
+
+            if typ.startswith("V-logit"):
+                Mv = st_v.M
+                d0 = self.drop(0.1)                          # BertForVLTasks.dropout on the region states (:1198)
+                xd = self.buf("task_xd", (Mv, H))
+                f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ADD_DROPOUT, p=(x_v, None, xd), n=(Mv, H, 0), f=(1.0,), drop=d0), None, None))
+                if tcfg.get("num_clf_layers", 1) == 2:       # Linear -> GELU -> Dropout -> Linear (:1138-1144)
+                    h, gp = self.buf("task_h", (Mv, H)), self.buf("task_gp", (Mv, H))
+                    self.gemm(f, L.NT, L.EPI_GELU, [self.prob(xd, self.W(pre + "0.weight"), h, Mv, H, H, H, H, H, bias=self.Pm(pre + "0.bias"), C2=gp)])
+                    d1 = self.drop(cfg.v_attention_probs_dropout_prob)
+                    hd = self.buf("task_hd", (Mv, H))
+                    f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ADD_DROPOUT, p=(h, None, hd), n=(Mv, H, 0), f=(1.0,), drop=d1), None, None))
+                    self.pred, self.d_pred, Cp = linear_out(hd, Mv, H, pre + "3.", 1)
+                    dhd, dh, du = self.buf("task_dhd", (Mv, H)), self.buf("task_dh", (Mv, H)), self.buf("task_du", (Mv, H))
+                    linear_bwd(self.d_pred, Cp, hd, Mv, H, pre + "3.", 1, dhd)
+                    b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ADD_DROPOUT, p=(dhd, None, dh), n=(Mv, H, 1), f=(1.0,), drop=d1), None, None))
+                    b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MUL, p=(dh, gp, du, None), n=(Mv * H, H)), None, None))
+                    dxd = self.buf("task_dxd", (Mv, H))
+                    linear_bwd(du, H, xd, Mv, H, pre + "0.", H, dxd)
+                else:
+                    self.pred, self.d_pred, Cp = linear_out(xd, Mv, H, pre, 1)
+                    dxd = self.buf("task_dxd", (Mv, H))
+                    linear_bwd(self.d_pred, Cp, xd, Mv, H, pre, 1, dxd)
+                b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ADD_DROPOUT, p=(dxd, None, dxh[1]), n=(Mv, H, 1), f=(1.0,), drop=d0), None, None))
+                self.pred_shape = (B, Rv, 1)
+            else:
+                if fm == "none":
+                    raise ValueError("task type %r needs a pooled output; fusion method 'none' has none (encoders.py:1192-1193)" % typ)
+                fuse = {"mul": L.FUSE_MUL, "sum": L.FUSE_SUM, "text": L.FUSE_TEXT, "vl-bert_vqa": L.FUSE_TEXT}[fm]
+                d0 = self.drop(0.1)                          # BertForVLTasks.dropout on the fused pooled vector (:1184-1191)
+                pooled = self.buf("pooled", (B, P))
+                f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_POOL_FWD, p=(pt, pv, pooled), n=(B, P, 0, fuse), drop=d0), None, None))
+                rows, K0 = (B // 2, 2 * P) if typ == "VL-binary-classifier" else (B, P)      # NLVR2 pairs: view(-1, 2 P) (:1202)
+                if typ == "VL-binary-classifier" and B % 2:
+                    raise ValueError("VL-binary-classifier pools pairs of samples: the batch size must be even")
+                dpooled = self.buf("d_pooled", (B, P))
+                if typ in ("VL-classifier", "VL-classifier-GQA", "VL-binary-classifier"):
+                    C = 2 if typ == "VL-binary-classifier" else int(tcfg["num_labels"])
+                    Hc = cfg.clf_hidden_size
+                    if Hc % 64 or Hc > 2048:
+                        raise NotImplementedError("clf_hidden_size must be a multiple of 64, <= 2048")
+                    hc, gpc = self.buf("task_h", (rows, Hc)), self.buf("task_gp", (rows, Hc))
+                    w0, lnn, w3 = pre + "logit_fc.0.", pre + "logit_fc.2.", pre + "logit_fc.3."
+                    self.gemm(f, L.NT, L.EPI_GELU, [self.prob(pooled, self.W(w0 + "weight"), hc, rows, Hc, K0, K0, K0, Hc, bias=self.Pm(w0 + "bias"), C2=gpc)])
+                    hn = self.buf("task_hn", (rows, Hc))
+                    mean, rstd = self.buf("task_mean", (rows,), torch.float32), self.buf("task_rstd", (rows,), torch.float32)
+                    la = L.LnArgs(_addr(hc), None, None, _addr(self.Pm(lnn + "weight")), _addr(self.Pm(lnn + "bias")), _addr(hn), None, _addr(mean), _addr(rstd), None,
+                                  rows, Hc, rows, 0, 1.0, nodrop, _mk_segs(nodrop, None))
+                    f.append((L.OP_LN_FWD, 0, 0, 0, self.k(la), None, None))
+                    self.pred, self.d_pred, Cp = linear_out(hn, rows, Hc, w3, C)
+                    dhn, dhc, du = self.buf("task_dhn", (rows, Hc)), self.buf("task_dhc", (rows, Hc)), self.buf("task_du", (rows, Hc))
+                    linear_bwd(self.d_pred, Cp, hn, rows, Hc, w3, C, dhn)
+                    part = self.buf("task_ln_partial", (L.lib.vk_ln_bwd_partial_rows(rows) * 2 * Hc,), torch.float32)
+                    lb = L.LnBwdArgs(_addr(dhn), _addr(hc), _addr(mean), _addr(rstd), _addr(self.Pm(lnn + "weight")), _addr(dhc), None, _addr(part),
+                                     _addr(self.G(lnn + "weight")), _addr(self.G(lnn + "bias")), None, rows, Hc, rows, 0, 1.0, 0, nodrop, _mk_segs(nodrop, None))
+                    b.append((L.OP_LN_BWD, 0, 0, 0, self.k(lb), None, None))
+                    b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MUL, p=(dhc, gpc, du, None), n=(rows * Hc, Hc)), None, None))
+                    linear_bwd(du, Hc, pooled, rows, K0, w0, Hc, dpooled)
+                else:                                         # VL-tri-classifier (3 classes), VL-logit (1 score): one Linear (:1134-1137)
+                    C = 3 if typ == "VL-tri-classifier" else 1
+                    self.pred, self.d_pred, Cp = linear_out(pooled, rows, K0, pre, C)
+                    linear_bwd(self.d_pred, Cp, pooled, rows, K0, pre, C, dpooled)
+                self.pred_shape = (rows, C)
+                dpool[0] = self.buf("d_pool_t", (B, P))
+                dpool[1] = self.buf("d_pool_v", (B, P)) if pv is not None else None
+                b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_POOL_BWD, p=(dpooled, pt, pv, dpool[0], dpool[1]), n=(B, P, P, fuse), drop=d0), None, None))
+        self.unused_params |= set(heads_of_other_tasks)      # the classifiers of the other tasks (and, for region-logit tasks, the poolers) get no gradient
+        for m, (xm, Lm, pre_p, py) in enumerate(((x_t, T, "bert.t_pooler.dense.", pt), (x_v, Rv, "bert.v_pooler.dense.", pv))):
             if py is None:
                 continue
-            dy_ = self.buf("d_pool_pre%d" % m, (B, P))
-            b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_RELU_BWD, p=(self.d_pool[m], py, dy_), n=(B * P,)), None, None))
+            if dpool[m] is None:
+                self.unused_params |= {pre_p + "weight", pre_p + "bias"}
+                continue
+            dy_ = dpool[m]
             if vqa is not None:                            # the pooled token differs per caption: gathered rows in, scatter-add out
                 dxg = self.buf("vqa_dx", (B, H))
-                self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dy_, self.W(pre + "weight"), dxg, B, H, P, P, H, H)])
-                b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SCATTER_ADD, p=(dxg, rows, cnt, dxh[0]), n=(H, B)), None, None))
-                self.gemm(b, L.TN, L.EPI_F32, [self.prob(dy_, xg, self.G(pre + "weight"), P, H, B, P, H, H, bias_grad=self.G(pre + "bias"))])
+                self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dy_, self.W(pre_p + "weight"), dxg, B, H, P, P, H, H)])
+                b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SCATTER_ADD, p=(dxg, vqa_rows, vqa_cnt, dxh[0]), n=(H, B)), None, None))
+                self.gemm(b, L.TN, L.EPI_F32, [self.prob(dy_, xg, self.G(pre_p + "weight"), P, H, B, P, H, H, bias_grad=self.G(pre_p + "bias"))])
             else:
-                self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dy_, self.W(pre + "weight"), dxh[m], B, H, P, P, H, Lm * H, R=dxh[m], ldr=Lm * H)])
-                self.gemm(b, L.TN, L.EPI_F32, [self.prob(dy_, xm, self.G(pre + "weight"), P, H, B, P, Lm * H, H, bias_grad=self.G(pre + "bias"))])
+                self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dy_, self.W(pre_p + "weight"), dxh[m], B, H, P, P, H, Lm * H, R=dxh[m], ldr=Lm * H)])
+                self.gemm(b, L.TN, L.EPI_F32, [self.prob(dy_, xm, self.G(pre_p + "weight"), P, H, B, P, Lm * H, H, bias_grad=self.G(pre_p + "bias"))])
         return b
 
     # ---------------------------------------------------------------- run

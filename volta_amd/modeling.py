@@ -293,12 +293,14 @@ class BertForVLPreTraining(PreTrainedModel):
         from .engine import StepEngine
         arena = self.materialize()
         fp8 = bool(self.__dict__.get("_fp8", False))
-        key = (B, T, Rv, bool(train), fp8)
+        task_id = self.__dict__.get("_cur_task")
+        key = (B, T, Rv, bool(train), fp8, task_id)
         eng = self._engines.get(key)
         if eng is None:
-            for k in [k for k in self._engines if k[3] == key[3]]:      # one plan per mode keeps memory bounded
+            for k in [k for k in self._engines if k[3] == key[3] and k[5] == task_id]:      # one plan per mode (and task head) keeps memory bounded
                 del self._engines[k]
-            eng = StepEngine(self.config, arena, B, T, Rv, train, heads=getattr(self, "_heads_mode", "pretrain"), fp8=fp8)
+            task = (task_id, self.task_cfg[task_id]) if task_id is not None else None
+            eng = StepEngine(self.config, arena, B, T, Rv, train, heads=getattr(self, "_heads_mode", "pretrain"), fp8=fp8, task=task)
             self._engines[key] = eng
         return eng
 
@@ -463,7 +465,8 @@ class BertForVLPreTraining(PreTrainedModel):
 
 # ======================================================================================== downstream tasks
 class SimpleClassifier(nn.Module):
-    """Linear -> GELU -> LayerNorm -> Linear (volta/encoders.py:787-815).  A few MFLOP on [B, pooler_size]: stock torch modules."""
+    """Linear -> GELU -> LayerNorm -> Linear (volta/encoders.py:787-815): the parameter container with the reference's names; the arithmetic
+    runs on the HIP engine (engine.py:_heads_tasks), `forward` is kept for reference use on CPU copies only."""
 
     def __init__(self, in_dim, hid_dim, out_dim, dropout_prob=0.0):
         super().__init__()
@@ -473,45 +476,36 @@ class SimpleClassifier(nn.Module):
         return self.logit_fc(hidden_states)
 
 
-class _TaskEncode(torch.autograd.Function):
-    """Encoder + poolers as one autograd node: the four outputs leave the engine as fp32 tensors, their gradients re-enter it."""
+class _TaskStep(torch.autograd.Function):
+    """Encoder + poolers + the task's classifier as one autograd node: the prediction leaves the engine as fp32 logits, its gradient
+    re-enters it as the seed of the backward list."""
 
     @staticmethod
     def forward(ctx, model, anchor, tensors):
         model._engine_forward(tensors)
         eng = model._last[0]
         ctx.model = model
-        B, T = tensors["input_ids"].shape
-        Rv = tensors["image_feat"].shape[1]
-        H = model.config.hidden_size
-        seq_t = eng.taps["seq_t"].view(B, T, H).float()
-        # a pooler the fusion method does not have (encoders.py:936-947) leaves an empty, non-differentiable placeholder
-        pooled = [seq_t.new_zeros(0) if eng.taps[k] is None else eng.taps[k].float() for k in ("pooled_t", "pooled_v")]
-        ctx.mark_non_differentiable(*[p for p in pooled if p.numel() == 0])
-        return seq_t, eng.taps["seq_v"].view(B, Rv, H).float(), pooled[0], pooled[1]
+        C = eng.pred_shape[-1]
+        return eng.pred[:, :C].reshape(eng.pred_shape).clone()
 
     @staticmethod
-    def backward(ctx, g_seq_t, g_seq_v, g_pt, g_pv):
+    def backward(ctx, g_pred):
         model = ctx.model
         eng, _ = model._last
         state = model._backward_begin(eng)
-        for dst, g in ((eng.d_seq[0], g_seq_t), (eng.d_seq[1], g_seq_v), (eng.d_pool[0], g_pt), (eng.d_pool[1], g_pv)):
-            if dst is None:
-                continue
-            if g is None:
-                dst.zero_()
-            else:
-                dst.copy_(g.reshape(dst.shape))
+        C = eng.pred_shape[-1]
+        eng.d_pred[:, :C].copy_(g_pred.reshape(-1, C))        # the pad columns stay zero
         model._backward_run(eng, state)
         return None, None, None
 
 
 class BertForVLTasks(PreTrainedModel):
-    """Fine-tuning / evaluation model of the downstream tasks (volta/encoders.py:1117-1206): the gated encoder runs on the HIP
-    engine (forward AND backward), the small task heads are torch modules on its pooled / region outputs."""
+    """Fine-tuning / evaluation model of the downstream tasks (volta/encoders.py:1117-1206): encoder, poolers, fusion + dropout and the
+    task's classifier all run on the HIP engine, forward and backward; `clfs_dict` holds the classifiers' parameters under the reference's
+    names and is never called."""
 
     _heads_mode = "tasks"
-    _torch_param_prefixes = ("clfs_dict.",)
+    _torch_param_prefixes = ()
     _vk_is_model = True
     materialize = BertForVLPreTraining.materialize
     _engine = BertForVLPreTraining._engine
@@ -525,7 +519,8 @@ class BertForVLTasks(PreTrainedModel):
     def __init__(self, config, task_cfg, task_ids, dropout_prob=0.1):
         super().__init__(config)
         self.bert = BertModel(config)
-        self.dropout = nn.Dropout(dropout_prob)
+        if dropout_prob != 0.1:
+            raise NotImplementedError("the engine's task heads use the reference's default dropout probability (0.1)")
         self.task_cfg = task_cfg
         task2clf = {}
         for task_id in task_ids:
@@ -570,22 +565,6 @@ class BertForVLTasks(PreTrainedModel):
                 mod.__dict__["_root"] = self
         for n, p in self.named_parameters():
             p._vk_owner = self
-            if n.startswith(self._torch_param_prefixes):
-                p.register_post_accumulate_grad_hook(self._redirect_head_grad)
-
-    def _redirect_head_grad(self, p):
-        """Gradients of the torch-side heads live in the flat gradient arena like every other one (clip / AdamW walk the arena)."""
-        arena = self.__dict__.get("_arena")
-        if arena is None or p.grad is None:
-            return
-        idx = self.__dict__.get("_head_index")
-        if idx is None or idx[0] is not arena:
-            idx = (arena, {id(q): g for (_, q), g in zip(arena.param_list(), arena.grad_views())})
-            self.__dict__["_head_index"] = idx
-        gv = idx[1][id(p)]
-        if p.grad is not gv:
-            gv.copy_(p.grad)
-            p.grad = gv
 
     def encode(self, input_ids, image_feat, image_loc, token_type_ids=None, attention_mask=None, image_attention_mask=None):
         """BertModel.forward under no_grad (BertModel.forward delegates here)."""
@@ -603,36 +582,25 @@ class BertForVLTasks(PreTrainedModel):
                 image_attention_mask=None, output_all_encoded_layers=False, output_all_attention_masks=False):
         if output_all_encoded_layers or output_all_attention_masks:
             raise NotImplementedError("intermediate layer / attention-map outputs are not materialised by the fused engine")
+        if task_id not in self.task_cfg or task_id not in self.clfs_dict:
+            raise KeyError("unknown task id %r" % (task_id,))
         tensors, B, T, Rv = self._prep_inputs(input_txt, input_imgs, image_loc, token_type_ids, attention_mask, image_attention_mask,
                                               None, None, None, None)
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.bert.parameters()):
+        self.__dict__["_cur_task"] = task_id                    # selects the plan whose head is this task's classifier
+        try:
             self.materialize()
-            anchor = next(p for p in self.bert.parameters() if p.requires_grad)
-            seq_t, seq_v, pooled_t, pooled_v = _TaskEncode.apply(self, anchor, tensors)
-        else:
-            self.materialize()
-            with torch.no_grad():
-                self._engine_forward(tensors)
-            eng = self._last[0]
-            H = self.config.hidden_size
-            seq_t, seq_v = eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, H).float()
-            pooled_t, pooled_v = [None if eng.taps[k] is None else eng.taps[k].float() for k in ("pooled_t", "pooled_v")]
-        if self.fusion_method == "sum":                          # encoders.py:1184-1195
-            pooled_output = self.dropout(pooled_t + pooled_v)
-        elif self.fusion_method == "mul":
-            pooled_output = self.dropout(pooled_t * pooled_v)
-        elif self.fusion_method in ("text", "vl-bert_vqa"):      # vl-bert_vqa: VLBertTextPooler's token (encoders.py:610-623), pooled by the engine
-            pooled_output = self.dropout(pooled_t)
-        elif self.fusion_method == "none":
-            pooled_output = None
-        else:
-            raise ValueError("Invalid fusion method: %s" % self.fusion_method)
-        task_type = self.task_cfg[task_id]["type"]
-        if task_type.startswith("V-logit"):
-            mask = tensors["image_attention_mask"].to(seq_v.dtype)
-            vil_prediction = self.clfs_dict[task_id](self.dropout(seq_v)) + ((1.0 - mask) * -10000.0).unsqueeze(2)
-        elif task_type == "VL-binary-classifier":
-            vil_prediction = self.clfs_dict[task_id](pooled_output.view(-1, pooled_output.size(1) * 2))
-        else:
-            vil_prediction = self.clfs_dict[task_id](pooled_output)
+            if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+                anchor = next(p for p in self.parameters() if p.requires_grad)
+                vil_prediction = _TaskStep.apply(self, anchor, tensors)
+            else:
+                with torch.no_grad():
+                    self._engine_forward(tensors)
+                eng = self._last[0]
+                C = eng.pred_shape[-1]
+                vil_prediction = eng.pred[:, :C].reshape(eng.pred_shape).clone()
+        finally:
+            self.__dict__["_cur_task"] = None
+        if self.task_cfg[task_id]["type"].startswith("V-logit"):   # padded regions are masked out of the region scores (encoders.py:1198-1199)
+            mask = tensors["image_attention_mask"].to(vil_prediction.dtype)
+            vil_prediction = vil_prediction + ((1.0 - mask) * -10000.0).unsqueeze(2)
         return vil_prediction, None, None, ([], [])
