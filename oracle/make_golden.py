@@ -169,6 +169,10 @@ def variant_configs():
                                visual_target_weights={"1": 2.0, "0": 0.5}, **enc)
     c["var_vqa_nce"] = dict(big, image_embeddings="vilbert", fusion_method="vl-bert_vqa", add_global_imgfeat=None,
                             visual_target_weights={"2": 1.5}, **enc)
+    # config/vilbert_base.json's geometry in small: a wider vision stream with its own head count and intermediate size, co-attention
+    # sub-layers that project BOTH streams to a third width (sublayer2attn_hidden_size / sublayer2num_attention_heads), equal poolers
+    c["var_wide"] = dict(TINY_BASE, image_embeddings="vilbert", v_hidden_size=96, v_num_attention_heads=3, v_intermediate_size=80,
+                         pooler_size=48, v_pooler_size=48, sublayer2attn_hidden_size={"4": 96}, sublayer2num_attention_heads={"4": 3}, **enc)
     return c
 
 
@@ -270,7 +274,7 @@ def write_variants(BertConfig, Model):
         np.savez_compressed(path, **blob)
         print(name, "losses", out["loss_lm"], out["loss_img"], out["loss_nsp"], os.path.getsize(path) // 1024, "KB", "no grad:", list(out["grad_none"]))
     # the two real non-ctrl configs that keep the 768-wide geometry, B=2 (weights from the seed generator, as write_ctrl)
-    for name, Rn in (("lxmert", 36), ("vl-bert_base", 36)):
+    for name, Rn in (("lxmert", 36), ("vl-bert_base", 36), ("vilbert_base", 36)):
         cd = json.load(open(os.path.join(REF, "config", name + ".json")))
         cfg = R.RefConfig(cd)
         sd = R.make_weights(cfg, seed=3, std=0.03)

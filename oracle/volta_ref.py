@@ -677,30 +677,36 @@ def param_shapes(cfg):
             has_t = n in cfg.tt_attn_sublayers or n in cfg.tv_attn_sublayers
             has_v = n in cfg.vv_attn_sublayers or n in cfg.vt_attn_sublayers
             shared = n in cfg.shared_sublayers and has_t and has_v
+            # per-sub-layer attention widths (encoders.py:189-206,364-366; config/vilbert_base.json: the co-attention sub-layers project both
+            # streams to 1024 = 8 heads of 128)
+            Ha = cfg.sublayer2attn_hidden_size.get(str(n), H)
+            Hva = cfg.sublayer2v_attn_hidden_size.get(str(n), Hv)
             if has_t:
                 for k in ("query", "key", "value"):
-                    lin(p + "attention_self." + k, H, H)
+                    lin(p + "attention_self." + k, Ha, H)
             if has_v and not shared:
                 for k in ("v_query", "v_key", "v_value"):
-                    lin(p + "attention_self." + k, Hv, Hv)
+                    lin(p + "attention_self." + k, Hva, Hv)
             if has_t:
-                lin(p + "attention_output.dense", H, H)
+                lin(p + "attention_output.dense", H, Ha)
                 ln(p + "attention_output.LayerNorm", H)
             if has_v and not shared:
-                lin(p + "attention_output.v_dense", Hv, Hv)
+                lin(p + "attention_output.v_dense", Hv, Hva)
                 ln(p + "attention_output.v_LayerNorm", Hv)
         else:
             has_t, has_v = n in cfg.t_ff_sublayers, n in cfg.v_ff_sublayers
             shared = n in cfg.shared_sublayers and has_t and has_v
+            In = cfg.sublayer2intermediate_size.get(str(n), I)
+            Ivn = cfg.sublayer2v_intermediate_size.get(str(n), Iv)
             if has_t:
-                lin(p + "intermediate.dense", I, H)
+                lin(p + "intermediate.dense", In, H)
             if has_v and not shared:
-                lin(p + "intermediate.v_dense", Iv, Hv)
+                lin(p + "intermediate.v_dense", Ivn, Hv)
             if has_t:
-                lin(p + "output.dense", H, I)
+                lin(p + "output.dense", H, In)
                 ln(p + "output.LayerNorm", H)
             if has_v and not shared:
-                lin(p + "output.v_dense", Hv, Iv)
+                lin(p + "output.v_dense", Hv, Ivn)
                 ln(p + "output.v_LayerNorm", Hv)
     fm = cfg.fusion_method
     if fm != "none":

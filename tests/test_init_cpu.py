@@ -50,3 +50,27 @@ def test_constructor_init_matches_reference_statistics(golden_dir, name):
     for group in json.loads(str(z["equal_groups"])):
         for k in group[1:]:
             assert torch.equal(sd[group[0]], sd[k]), (group[0], k)
+
+
+def test_wide_config_is_a_parameter_drop_in(golden_dir):
+    """config/vilbert_base.json (1024-wide vision stream, 8 heads of 128, per-sub-layer attention widths): the product model's parameter
+    tree has the reference's keys, order, shapes and count; the HIP engine does not run this geometry yet and says so."""
+    import json
+    import os
+
+    import numpy as np
+    import pytest
+    pytest.importorskip("volta_amd._lib", reason="libvolta_hip.so not built")
+    from oracle import volta_ref as R
+    from volta_amd.config import BertConfig
+    from volta_amd.modeling import BertForVLPreTraining
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "config", "vilbert_base.json")
+    model = BertForVLPreTraining(BertConfig.from_json_file(path))
+    z = np.load(os.path.join(golden_dir, "full_vilbert_base.npz"))
+    assert list(model.state_dict().keys()) == [str(k) for k in z["ref_keys"]]
+    assert sum(p.numel() for p in model.parameters()) == int(z["n_params"][0])
+    shapes = R.param_shapes(R.RefConfig(json.load(open(path))))
+    for k, v in model.state_dict().items():
+        if k in shapes:
+            assert tuple(v.shape) == tuple(shapes[k]), k

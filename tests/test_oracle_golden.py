@@ -194,7 +194,7 @@ def test_philox_known_answer():
 
 
 # ---- the other fusion methods / global-feature placements / visual targets
-VARIANTS = ["var_lxmert_text", "var_vlbert_none", "var_sum_mse_kl", "var_vqa_nce"]
+VARIANTS = ["var_lxmert_text", "var_vlbert_none", "var_sum_mse_kl", "var_vqa_nce", "var_wide"]
 
 
 def _variant(z):
@@ -250,10 +250,11 @@ def test_variant_heads_match_reference(golden_dir, name):
     np.testing.assert_allclose(total, z["out::grad_norm"][0], rtol=2e-5)
 
 
-@pytest.mark.parametrize("name", ["lxmert", "vl-bert_base"])
+@pytest.mark.parametrize("name", ["lxmert", "vl-bert_base", "vilbert_base"])
 def test_non_ctrl_config_matches_reference(golden_dir, name):
-    """config/lxmert.json (text fusion, xent_1600 + xent_400 + huber_2048) and config/vl-bert_base.json (no fusion, global feature last,
-    xent_1601 + the masked-region word embedding) at full width, B=2."""
+    """config/lxmert.json (text fusion, xent_1600 + xent_400 + huber_2048), config/vl-bert_base.json (no fusion, global feature last,
+    xent_1601 + the masked-region word embedding) and config/vilbert_base.json (1024-wide vision stream with 8 heads of 128, co-attention
+    sub-layers at 1024 / 8 heads for both streams) at full width, B=2."""
     z = load(golden_dir, "full_" + name)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = R.RefConfig.from_json_file(os.path.join(root, "config", name + ".json"))
