@@ -197,6 +197,8 @@ typedef struct vk_attn_args {
     int32_t gate[2][2];
     vk_dropout drop[2][2];   /* one dropout site per score block, as in the reference */
     float scale;             /* 1/sqrt(head size) */
+    int32_t dh;              /* head size: 0 or 64 -> the MFMA kernels (every ctrl_* config); 32, 96, 128 -> the generic kernels
+                                (config/vilbert_base.json: 8 heads of 128), column h * dh of q / k / v / ctx is head h */
 } vk_attn_args;
 typedef struct vk_attn_bwd_args {
     const void* dctx[2];     /* bf16 [B*L[m], ldo[m]] gradient of ctx */

@@ -10,19 +10,19 @@ GATES = {"tt": [[1, 0], [0, 0]], "tt+vv": [[1, 0], [0, 1]], "tv+vt": [[0, 1], [1
          "tt+tv": [[1, 1], [0, 0]]}
 
 
-def reference(q, k, v, masks, gate, B, nh, L, keep):
-    """q/k/v[m]: [B, nh, L[m], 64] fp32 leaf tensors.  Returns ctx[m] [B, L[m], nh*64]."""
+def reference(q, k, v, masks, gate, B, nh, L, keep, dh=64):
+    """q/k/v[m]: [B, nh, L[m], dh] fp32 leaf tensors.  Returns ctx[m] [B, L[m], nh*dh]."""
     out = [None, None]
     for mq in range(2):
         blocks = [mk for mk in range(2) if gate[mq][mk]]
         if not blocks:
             continue
-        sc = [q[mq] @ k[mk].transpose(-1, -2) / 8.0 + masks[mk][:, None, None, :] for mk in blocks]
+        sc = [q[mq] @ k[mk].transpose(-1, -2) / (dh ** 0.5) + masks[mk][:, None, None, :] for mk in blocks]
         pr = torch.softmax(torch.cat(sc, -1), -1).split([s.shape[-1] for s in sc], -1)
         ctx = 0
         for p, mk in zip(pr, blocks):
             ctx = ctx + (p * keep[mq][mk]) @ v[mk]
-        out[mq] = ctx.transpose(1, 2).reshape(B, L[mq], nh * 64)
+        out[mq] = ctx.transpose(1, 2).reshape(B, L[mq], nh * dh)
     return out
 
 
@@ -30,10 +30,23 @@ def reference(q, k, v, masks, gate, B, nh, L, keep):
 @pytest.mark.parametrize("T,R", [(20, 37), (38, 37), (20, 101), (6, 4)])
 @pytest.mark.parametrize("train", [False, True])
 def test_gated_attention(gname, T, R, train):
+    _run(gname, T, R, train, 12, 64)
+
+
+@pytest.mark.parametrize("gname", list(GATES))
+@pytest.mark.parametrize("T,R,nh,dh", [(20, 37, 8, 128), (38, 101, 8, 128), (6, 4, 3, 32), (20, 37, 4, 96)])
+@pytest.mark.parametrize("train", [False, True])
+def test_gated_attention_other_head_sizes(gname, T, R, nh, dh, train):
+    """config/vilbert_base.json's 8 heads of 128 (vision stream and co-attention sub-layers) and the other sizes of the generic kernels
+    (csrc/attention_generic.hip): same contract, same dropout stream as the 64-wide MFMA kernels."""
+    _run(gname, T, R, train, nh, dh)
+
+
+def _run(gname, T, R, train, nh, dh):
     from volta_amd import _lib as L_, ops
     from oracle import volta_ref as Rf
     gate = GATES[gname]
-    B, nh, H = 3, 12, 768
+    B, H = 3, nh * dh
     Ls = [T, R]
     g = torch.Generator().manual_seed(T * 100 + R)
     qkv = [(torch.randn(B * Ls[m], 3 * H, generator=g) * 1.5).bfloat16() for m in range(2)]
@@ -49,14 +62,14 @@ def test_gated_attention(gname, T, R, train):
     qkv_d = [t.to(dev) for t in qkv]
     ctx_d = [torch.zeros(B * Ls[m], H, device=dev, dtype=torch.bfloat16) for m in range(2)]
     lse_d = [torch.zeros(B * nh * Ls[m], device=dev) for m in range(2)]
-    a = ops.attn_args(qkv_d, Ls, [m.to(dev) for m in masks], ctx_d, lse_d, B, nh, gate, drops, H)
+    a = ops.attn_args(qkv_d, Ls, [m.to(dev) for m in masks], ctx_d, lse_d, B, nh, gate, drops, H, dh=dh)
     ops.attn_fwd(a)
     dqkv_d = [torch.zeros(B * Ls[m], 3 * H, device=dev, dtype=torch.bfloat16) for m in range(2)]
     ops.attn_bwd(a, [t.to(dev) for t in dctx], dqkv_d, Ls, B, gate, H)
     torch.cuda.synchronize()
 
     def heads(t, m, i):
-        return t.float()[:, i * H:(i + 1) * H].reshape(B, Ls[m], nh, 64).transpose(1, 2).contiguous().requires_grad_(True)
+        return t.float()[:, i * H:(i + 1) * H].reshape(B, Ls[m], nh, dh).transpose(1, 2).contiguous().requires_grad_(True)
 
     q = [heads(qkv[m], m, 0) for m in range(2)]
     k = [heads(qkv[m], m, 1) for m in range(2)]
@@ -64,7 +77,7 @@ def test_gated_attention(gname, T, R, train):
     keep = [[1.0, 1.0], [1.0, 1.0]]
     if train:
         keep = [[Rf.philox_keep_mask(seed, sites[i][j], (B, nh, Ls[i], Ls[j]), p).float() / (1 - p) for j in range(2)] for i in range(2)]
-    ref = reference(q, k, v, masks, gate, B, nh, Ls, keep)
+    ref = reference(q, k, v, masks, gate, B, nh, Ls, keep, dh)
     loss = 0
     for m in range(2):
         if ref[m] is not None:

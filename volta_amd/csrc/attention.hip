@@ -527,8 +527,11 @@ static int launch_bwd(const AttnK& k, int ntasks, hipStream_t s) {
 
 }  // namespace vk
 
+namespace vk { int attn_generic(const vk_attn_args* a, const vk_attn_bwd_args* bw, vk_stream_t stream); }      // attention_generic.hip
+
 extern "C" int vk_gated_attn_fwd(const vk_attn_args* a, vk_stream_t stream) {
     using namespace vk;
+    if (a->dh != 0 && a->dh != DH) return attn_generic(a, nullptr, stream);
     AttnK k;
     if (int rc = fill(k, a, nullptr)) return rc;
     if (a->B <= 0) return 0;
@@ -544,6 +547,7 @@ extern "C" int vk_gated_attn_fwd(const vk_attn_args* a, vk_stream_t stream) {
 
 extern "C" int vk_gated_attn_bwd(const vk_attn_args* a, const vk_attn_bwd_args* bw, vk_stream_t stream) {
     using namespace vk;
+    if (a->dh != 0 && a->dh != DH) return attn_generic(a, bw, stream);
     AttnK k;
     if (int rc = fill(k, a, bw)) return rc;
     if (a->B <= 0) return 0;

@@ -103,10 +103,11 @@ def ln_bwd(dy, z, mean, rstd, gamma, dz, dd, partial, dgamma, dbeta, M, H, drop=
     check(L.lib.vk_ln_bwd(C.byref(a), stream_ptr()))
 
 
-def attn_args(qkv, L, masks, ctx, lse, B, nh, gate, drops=None, H=None):
-    """qkv[m]: [B*L[m], 3H] fused projection output (Q | K | V column blocks); ctx[m]: [B*L[m], H]."""
+def attn_args(qkv, L, masks, ctx, lse, B, nh, gate, drops=None, H=None, dh=64):
+    """qkv[m]: [B*L[m], 3H] fused projection output (Q | K | V column blocks); ctx[m]: [B*L[m], H]; H = nh * dh."""
     a = L_.AttnArgs()
-    H = H or nh * 64
+    H = H or nh * dh
+    assert H == nh * dh
     for m in range(2):
         used_q = gate[m][0] or gate[m][1]
         used_k = gate[0][m] or gate[1][m]
@@ -128,7 +129,7 @@ def attn_args(qkv, L, masks, ctx, lse, B, nh, gate, drops=None, H=None):
             a.ctx[m] = ctx[m].data_ptr()
             a.ldo[m] = H
             a.lse[m] = lse[m].data_ptr()
-    a.B, a.nh, a.scale = B, nh, 0.125
+    a.B, a.nh, a.scale, a.dh = B, nh, 1.0 / (dh ** 0.5), dh
     for i in range(2):
         for j in range(2):
             a.gate[i][j] = int(bool(gate[i][j]))
