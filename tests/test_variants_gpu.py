@@ -35,6 +35,10 @@ VARIANTS = {
     "vqa_nce": dict(BIG, image_embeddings="vilbert", fusion_method="vl-bert_vqa", add_global_imgfeat=None,
                     visual_target_weights={"2": 1.5}, **ENC),
     "mul_last_two": dict(BASE, image_embeddings="uniter", add_global_imgfeat="last", visual_target_weights={"6": 0.7, "0": 1.0}, **SINGLE),
+    # config/vilbert_base.json's geometry at reduced depth: 768 / 12 x 64 text, 1024 / 8 x 128 vision with a 1024-wide feed-forward, a
+    # co-attention sub-layer that projects both streams to 1024 = 8 x 128, a sub-layer with text AND vision self-attention of different heads
+    "wide_vilbert": dict(BASE, image_embeddings="vilbert", v_hidden_size=1024, v_num_attention_heads=8, v_intermediate_size=1024,
+                         sublayer2attn_hidden_size={"2": 1024}, sublayer2num_attention_heads={"2": 8}, **ENC),
 }
 
 
@@ -106,36 +110,51 @@ def test_variant_forward_backward_parity(name, train):
         assert abs(g - r) <= tol * max(abs(r), 1e-3) + 1e-4, (name, nm, g, r)
     assert float(oimg.detach()) > 0
     named = dict(model.named_parameters())
-    (lm + img + nsp).sum().backward()
-    (olm + oimg + onsp).sum().backward()
-    torch.cuda.synchronize()
-    bad = []
     # feature-regression / nce targets: d loss / d prediction = (prediction - feature) or a softmax over <feature, prediction>, both differences
     # of quantities that carry the bf16 noise of the 2048-wide prediction -- observed 4.5-5.6e-2 / cosine 0.9984 where the
     # hard-label targets give 1e-2 / 0.9999
     regress = bool(set(cd["visual_target_weights"]) & {"1", "2", "5"})
-    tol, min_cos = (8e-2, 0.997) if regress else (6e-2, 0.998)      # two-target uniter variant in training mode: 4.7e-2 / 0.9989 observed
-    for k, leaf in leaves.items():
-        if leaf.grad is None:                      # the reference's autograd leaves these parameters alone: so must the engine
-            assert named[k].grad is None, (name, k)
-            continue
-        assert named[k].grad is not None, (name, k)
-        g_ref, g_got = leaf.grad, named[k].grad.float().cpu()
-        assert torch.isfinite(g_got).all(), (name, k)
-        # key biases: identically zero by the softmax's shift invariance (the reference leaves 1e-6-sized rounding residue); the engine's residue
-        # is the column sum of bf16-rounded dK rows -- bounded against the query bias of the same sub-layer, whose gradient is the same kind of sum
-        scale = float(leaves[k.replace("key.", "query.")].grad.norm()) if k.endswith("key.bias") else 0.0
-        if float(g_ref.norm()) < 1e-6 + 1e-4 * scale:
-            if float(g_got.norm()) > 5e-3 + 0.3 * scale:
-                bad.append((k, "expected ~0", float(g_got.norm()), scale))
-            continue
-        e = rel_err(g_got, g_ref)
-        cos = float((g_got * g_ref).sum() / (g_got.norm() * g_ref.norm()))
-        itm_only = k.startswith(("bert.t_pooler", "bert.v_pooler", "cls.bi_seq"))
-        qk = "query." in k or "key." in k
-        if e > (0.5 if itm_only else max(0.1, tol) if qk else tol) or cos < (0.9 if itm_only else 0.995 if qk else min_cos):
-            bad.append((k, e, cos, float(g_ref.norm())))
-    assert not bad, (name, train, bad[:12], len(bad))
+    # gradients once for the MLM + region losses, once for the ITM loss (B x 2 logits: the forward bf16 noise shows up as a common scale
+    # error, rel. error 0.2-0.4 at B = 4; its tight gate is the B = 32 reference fixture of tests/test_fullsize_golden_gpu.py)
+    passes = [("lm+img", (8e-2, 0.997) if regress else (6e-2, 0.998))]
+    if float(onsp.detach()) != 0.0:
+        passes.append(("nsp", (0.5, 0.9)))
+    for which, (tol, min_cos) in passes:
+        for p in named.values():
+            p.grad = None
+        for leaf in leaves.values():
+            leaf.grad = None
+        if which == "nsp":
+            nsp.sum().backward()
+            onsp.sum().backward()
+        else:
+            (lm + img).sum().backward(retain_graph=True)
+            (olm + oimg).sum().backward(retain_graph=True)
+        torch.cuda.synchronize()
+        bad = []
+        for k, leaf in leaves.items():
+            if leaf.grad is None:                      # the reference's autograd leaves these parameters alone: so must the engine
+                if which == "lm+img" and not k.startswith(("bert.t_pooler", "bert.v_pooler", "cls.bi_seq")):
+                    assert named[k].grad is None or float(named[k].grad.float().norm()) == 0.0, (name, k)
+                continue
+            if named[k].grad is None:
+                bad.append((k, "no gradient"))
+                continue
+            g_ref, g_got = leaf.grad, named[k].grad.float().cpu()
+            assert torch.isfinite(g_got).all(), (name, k)
+            # key biases: identically zero by the softmax's shift invariance (the reference leaves 1e-6-sized rounding residue); the engine's residue
+            # is the column sum of bf16-rounded dK rows -- bounded against the query bias of the same sub-layer, whose gradient is the same kind of sum
+            scale = float(leaves[k.replace("key.", "query.")].grad.norm()) if k.endswith("key.bias") and leaves[k.replace("key.", "query.")].grad is not None else 0.0
+            if float(g_ref.norm()) < 1e-6 + 1e-4 * scale:
+                if float(g_got.norm()) > 5e-3 + 0.3 * scale:
+                    bad.append((k, "expected ~0", float(g_got.norm()), scale))
+                continue
+            e = rel_err(g_got, g_ref)
+            cos = float((g_got * g_ref).sum() / (g_got.norm() * g_ref.norm()))
+            qk = "query." in k or "key." in k
+            if e > (max(0.1, tol) if qk else tol) or cos < (min(0.995, min_cos) if qk else min_cos):
+                bad.append((k, e, cos, float(g_ref.norm())))
+        assert not bad, (name, train, which, bad[:12], len(bad))
 
 
 def test_variant_training_step_skips_unused_parameters():
@@ -163,7 +182,7 @@ def test_variant_training_step_skips_unused_parameters():
     assert last[0] + last[1] < first[0] + first[1] and last[2] == 0.0
 
 
-@pytest.mark.parametrize("name", ["lxmert", "vl-bert_base"])
+@pytest.mark.parametrize("name", ["lxmert", "vl-bert_base", "vilbert_base"])
 def test_non_ctrl_config_matches_reference_fixture(golden_dir, name):
     from volta_amd.config import BertConfig
     from volta_amd.modeling import BertForVLPreTraining
@@ -185,10 +204,10 @@ def test_non_ctrl_config_matches_reference_fixture(golden_dir, name):
         want = float(z["out::" + key][0])
         report[key] = abs(float(got) - want) / max(abs(want), 1e-6) if want else abs(float(got))
     eng = model._last[0]
-    H = 768
+    H, Hv = rcfg.hidden_size, rcfg.v_hidden_size
     report["seq_t"] = rel_err(eng.taps["seq_t"].float().cpu().view(2, 20, H)[:, :, :64], torch.from_numpy(z["out::seq_t_slice"]))
     Rv = eng.Rv
-    report["seq_v"] = rel_err(eng.taps["seq_v"].float().cpu().view(2, Rv, H)[:, :8, :64], torch.from_numpy(z["out::seq_v_slice"]))
+    report["seq_v"] = rel_err(eng.taps["seq_v"].float().cpu().view(2, Rv, Hv)[:, :8, :64], torch.from_numpy(z["out::seq_v_slice"]))
     # B = 2: MLM / region losses 1.5e-3 (as the ctrl fixtures at B = 2), ITM 3e-2 (two samples of bf16-noisy logits)
     assert report["loss_lm"] <= 1.5e-3 and report["loss_img"] <= 3e-3 and report["loss_nsp"] <= 3e-2, report
     assert report["seq_t"] <= 2e-2 and report["seq_v"] <= 2e-2, report

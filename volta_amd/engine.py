@@ -247,12 +247,18 @@ class StepEngine:
         dev = arena.device
         self.dev = dev
         H, Hv = cfg.hidden_size, cfg.v_hidden_size
-        if H != Hv or H % 256 or H // cfg.num_attention_heads != 64 or cfg.num_attention_heads != cfg.v_num_attention_heads:
-            raise NotImplementedError("the HIP engine covers the ctrl_* geometry: hidden == v_hidden, multiple of 256, "
-                                      "head size 64 (got %d / %d, %d heads)" % (H, Hv, cfg.num_attention_heads))
-        if cfg.sublayer2attn_hidden_size or cfg.sublayer2num_attention_heads or cfg.sublayer2intermediate_size or \
-                cfg.sublayer2v_attn_hidden_size or cfg.sublayer2v_num_attention_heads or cfg.sublayer2v_intermediate_size:
-            raise NotImplementedError("per-sub-layer sizes (non-ctrl configs) are out of scope (SURVEY.md 8f-4)")
+        # Widths: the two streams may differ (config/vilbert_base.json: 768 text, 1024 vision) and an attention sub-layer may project to a
+        # width of its own (sublayer2attn_hidden_size); every width is a multiple of 64, LayerNorm widths at most 1024.  Head sizes: 64 on
+        # the MFMA attention kernels, 32 / 96 / 128 on the generic ones.
+        if H % 64 or Hv % 64 or H > 1024 or Hv > 1024:
+            raise NotImplementedError("hidden sizes must be multiples of 64, at most 1024 (got %d / %d)" % (H, Hv))
+        self.wide = H != Hv or bool(cfg.sublayer2attn_hidden_size or cfg.sublayer2num_attention_heads or cfg.sublayer2intermediate_size or
+                                    cfg.sublayer2v_attn_hidden_size or cfg.sublayer2v_num_attention_heads or cfg.sublayer2v_intermediate_size) or \
+            H // cfg.num_attention_heads != 64 or Hv // cfg.v_num_attention_heads != 64
+        if self.wide and fp8:
+            raise NotImplementedError("the fp8 projection path covers the single-width (ctrl_*) geometry")
+        if self.wide and cfg.image_embeddings != "vilbert":
+            raise NotImplementedError("different stream widths are built for the ViLBERT embeddings (config/vilbert_base.json)")
         if cfg.hidden_act != "gelu" or cfg.v_hidden_act != "gelu":
             raise NotImplementedError("engine supports gelu activations (every reference config)")
         if cfg.fusion_method not in ("mul", "sum", "text", "vl-bert_vqa", "none"):
@@ -261,7 +267,7 @@ class StepEngine:
         if T > 64 or Rv > 128:
             raise NotImplementedError("sequence lengths above (64, 128) exceed the attention tile budget")
         self.H, self.I, self.nh = H, cfg.intermediate_size, cfg.num_attention_heads
-        self.st = [Stream(T, B, H), Stream(Rv, B, H)]
+        self.st = [Stream(T, B, H), Stream(Rv, B, Hv)]
         self.R = Rv - (1 if cfg.add_global_imgfeat is not None else 0)
         self.bufs = {}
         self.keep = []
@@ -356,10 +362,10 @@ class StepEngine:
         g.drop = drop or L.dropout_cfg(None, 0, 0.0)
         return self.k(g)
 
-    def ln_args(self, d, x, gname, bname, y, z, mean, rstd, M, drop, post=0, out_scale=1.0, addvec=None, dyn=None, segs=None, fp8_out=None):
+    def ln_args(self, d, x, gname, bname, y, z, mean, rstd, M, drop, post=0, out_scale=1.0, addvec=None, dyn=None, segs=None, fp8_out=None, H=None):
         """fp8_out = (q uint8 [M, ld8], scale fp32 [M]): the kernel also leaves a row-quantised e4m3 copy of y (the next projection's A operand)."""
         a = L.LnArgs(_addr(d), _addr(x), _addr(addvec), _addr(self.Pm(gname)), _addr(self.Pm(bname)), _addr(y), _addr(z), _addr(mean),
-                     _addr(rstd), _addr(dyn), M, self.H, M, post, out_scale, drop, _mk_segs(drop, segs))
+                     _addr(rstd), _addr(dyn), M, H or self.H, M, post, out_scale, drop, _mk_segs(drop, segs))
         if fp8_out is not None:
             a.y8, a.y8_scale, a.ld8 = _addr(fp8_out[0]), _addr(fp8_out[1]), fp8_out[0].stride(0)
         return self.k(a)
@@ -373,21 +379,24 @@ class StepEngine:
             q.zero_()
         return q, self.tmp("fp8_xs%d" % m, (M,), torch.float32)
 
-    def ln_bwd_args(self, dy, z, mean, rstd, gname, bname, dz, dd, M, drop, post=0, out_scale=1.0, dyn=None, segs=None, accumulate=0, defer=False, own_partial=False):
+    def ln_bwd_args(self, dy, z, mean, rstd, gname, bname, dz, dd, M, drop, post=0, out_scale=1.0, dyn=None, segs=None, accumulate=0, defer=False, own_partial=False,
+                    H=None):
         """`defer`: the dgamma / dbeta column reduction is left to an OP_LN_FINALIZE that the next _wgrad() places in its
         side-stream block; the partial records then need a buffer of their own.  `own_partial`: this launch runs inside a side-stream
         block, next to main-stream LayerNorm backwards -- it cannot share their scratch records either."""
+        H = H or self.H
+        Hmax = max(self.st[0].H, self.st[1].H)
         if (own_partial or getattr(self, "_aside", "")) and not defer:
             self._n_ln_partial = getattr(self, "_n_ln_partial", 0) + 1
-            partial = self.buf("ln_partial_%d" % self._n_ln_partial, (L.lib.vk_ln_bwd_partial_rows(M) * 2 * self.H,), torch.float32)
+            partial = self.buf("ln_partial_%d" % self._n_ln_partial, (L.lib.vk_ln_bwd_partial_rows(M) * 2 * H,), torch.float32)
         elif defer:
             self._n_ln_partial = getattr(self, "_n_ln_partial", 0) + 1
-            partial = self.buf("ln_partial_%d" % self._n_ln_partial, (L.lib.vk_ln_bwd_partial_rows(M) * 2 * self.H,), torch.float32)
+            partial = self.buf("ln_partial_%d" % self._n_ln_partial, (L.lib.vk_ln_bwd_partial_rows(M) * 2 * H,), torch.float32)
             accumulate |= 2
         else:
-            partial = self.tmp("ln_partial", (L.lib.vk_ln_bwd_partial_rows(max(self.st[0].M, self.st[1].M)) * 2 * self.H,), torch.float32)
+            partial = self.tmp("ln_partial", (L.lib.vk_ln_bwd_partial_rows(max(self.st[0].M, self.st[1].M)) * 2 * Hmax,), torch.float32)
         a = L.LnBwdArgs(_addr(dy), _addr(z), _addr(mean), _addr(rstd), _addr(self.Pm(gname)), _addr(dz), _addr(dd), _addr(partial),
-                        _addr(self.G(gname)), _addr(self.G(bname)), _addr(dyn), M, self.H, M, post, out_scale, accumulate, drop,
+                        _addr(self.G(gname)), _addr(self.G(bname)), _addr(dyn), M, H, M, post, out_scale, accumulate, drop,
                         _mk_segs(drop, segs))
         a = self.k(a)
         if defer:
@@ -484,7 +493,7 @@ class StepEngine:
     # its input to buffer (k-1)%2; the embeddings read buffer 0, the heads fill buffer (final k)%2.
     def _dx(self, m, parity):
         aside, self._aside = getattr(self, "_aside", ""), ""          # the hidden-state gradients are shared by definition
-        t = self.tmp("dx%d_%d" % (m, parity), (self.st[m].M, self.H))
+        t = self.tmp("dx%d_%d" % (m, parity), (self.st[m].M, self.st[m].H))
         self._aside = aside
         return t
 
@@ -528,8 +537,8 @@ class StepEngine:
         return b
 
     def _img_proj(self, pre, wname, tag):
-        """feat (fp32) -> bf16 -> [Mv, H] = feat W^T + b ; returns (proj, feat_bf16)."""
-        cfg, st, H = self.cfg, self.st[1], self.H
+        """feat (fp32) -> bf16 -> [Mv, Hv] = feat W^T + b ; returns (proj, feat_bf16)."""
+        cfg, st, H = self.cfg, self.st[1], self.st[1].H
         f = self.fwd.ops
         F_ = cfg.v_feature_size
         if F_ % 64:
@@ -543,7 +552,7 @@ class StepEngine:
         return proj, featb
 
     def _loc_proj(self, pre, tag):
-        cfg, st, H = self.cfg, self.st[1], self.H
+        cfg, st, H = self.cfg, self.st[1], self.st[1].H
         out = self.buf(tag + "_locproj", (st.M, H))
         g = self.generic(L.FN_LOC_FWD, p=(None, self.Pm(pre + "image_location_embeddings.weight"), self.Pm(pre + "image_location_embeddings.bias"), out),
                          n=(st.M, H, cfg.num_locs))
@@ -552,11 +561,11 @@ class StepEngine:
         return out
 
     def _img_proj_bwd(self, b, pre, wname, dz, featb):
-        st, H, F_ = self.st[1], self.H, self.cfg.v_feature_size
+        st, H, F_ = self.st[1], self.st[1].H, self.cfg.v_feature_size
         self.gemm(b, L.TN, L.EPI_F32, [self.prob(dz, featb, self.G(pre + wname + ".weight"), H, F_, st.M, H, F_, F_, bias_grad=self.G(pre + wname + ".bias"))])
 
     def _loc_proj_bwd(self, b, pre, dz):
-        st, H = self.st[1], self.H
+        st, H = self.st[1], self.st[1].H
         part = self.tmp("loc_partial", (L.lib.vk_rows32(st.M) * 9 * H,), torch.float32)
         g = self.generic(L.FN_LOC_BWD, p=(dz, None, part, self.G(pre + "image_location_embeddings.weight"), self.G(pre + "image_location_embeddings.bias")),
                          n=(st.M, H, self.cfg.num_locs))
@@ -564,17 +573,17 @@ class StepEngine:
         b.append((L.OP_GENERIC, 0, 0, 0, g, None, None))
 
     def _emb_image_vilbert(self, pre):
-        cfg, st, H = self.cfg, self.st[1], self.H
+        cfg, st, H = self.cfg, self.st[1], self.st[1].H
         proj, featb = self._img_proj(pre, "image_embeddings", "emb_v")
         loc = self._loc_proj(pre, "emb_v")
         y = self.buf("emb_v_y", (st.M, H))
         mean, rstd = self.buf("emb_v_mean", (st.M,), torch.float32), self.buf("emb_v_rstd", (st.M,), torch.float32)
         dr = self.drop(cfg.v_hidden_dropout_prob)
-        self.fwd.ops.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(proj, loc, pre + "LayerNorm.weight", pre + "LayerNorm.bias", y, proj, mean, rstd, st.M, dr, post=1), None, None))
+        self.fwd.ops.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(proj, loc, pre + "LayerNorm.weight", pre + "LayerNorm.bias", y, proj, mean, rstd, st.M, dr, post=1, H=H), None, None))
         self.x[1] = y
         b = []
         dz = self.tmp("dz1", (st.M, H))
-        b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(self._dx(1, 0), proj, mean, rstd, pre + "LayerNorm.weight", pre + "LayerNorm.bias", dz, None, st.M, dr, post=1), None, None))
+        b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(self._dx(1, 0), proj, mean, rstd, pre + "LayerNorm.weight", pre + "LayerNorm.bias", dz, None, st.M, dr, post=1, H=H), None, None))
         self._img_proj_bwd(b, pre, "image_embeddings", dz, featb)
         self._loc_proj_bwd(b, pre, dz)
         return b
@@ -810,7 +819,7 @@ class StepEngine:
         return out, shared
 
     def _attn_sublayer(self, n):
-        cfg, H, B, nh = self.cfg, self.H, self.B, self.nh
+        cfg, B = self.cfg, self.B
         f = self.fwd.ops
         gate = [[int(n in cfg.tt_attn_sublayers), int(n in cfg.tv_attn_sublayers)], [int(n in cfg.vt_attn_sublayers), int(n in cfg.vv_attn_sublayers)]]
         act = [bool(gate[0][0] or gate[0][1]), bool(gate[1][0] or gate[1][1])]
@@ -819,34 +828,40 @@ class StepEngine:
         tag = "L%d_" % n
         x_in = list(self.x)
         x8_in = list(self.x8)
-        qkv = {m: self.buf(tag + "qkv%d" % m, (self.st[m].M, 3 * H)) for m in ms}
-        ctx = {m: self.buf(tag + "ctx%d" % m, (self.st[m].M, H)) for m in ms}
-        lse = {m: self.buf(tag + "lse%d" % m, (B * nh * self.st[m].L,), torch.float32) for m in ms}
-        d = {m: self.buf(tag + "z%d" % m, (self.st[m].M, H)) for m in ms}
-        y = {m: self.buf(tag + "y%d" % m, (self.st[m].M, H)) for m in ms}
+        # widths: Hm = the stream's hidden size, Ha = the sub-layer's attention width for that stream, nhm heads of dh (encoders.py:164-206)
+        Hm = [self.st[0].H, self.st[1].H]
+        Ha = [cfg.sublayer2attn_hidden_size.get(str(n), cfg.hidden_size), cfg.sublayer2v_attn_hidden_size.get(str(n), cfg.v_hidden_size)]
+        nhm = [cfg.sublayer2num_attention_heads.get(str(n), cfg.num_attention_heads), cfg.sublayer2v_num_attention_heads.get(str(n), cfg.v_num_attention_heads)]
+        dh = [Ha[m] // nhm[m] for m in range(2)]
+        for m in ms:
+            if Ha[m] % nhm[m] or dh[m] not in (32, 64, 96, 128) or Ha[m] % 64:
+                raise NotImplementedError("attention width %d with %d heads (head sizes 32, 64, 96, 128; widths multiples of 64)" % (Ha[m], nhm[m]))
+        cross = gate[0][1] or gate[1][0]
+        if shared and len(ms) == 2 and (Hm[0] != Hm[1] or Ha[0] != Ha[1]):
+            raise ValueError("a shared attention sub-layer needs equal widths in both streams")
+        if cross and (dh[0] != dh[1] or nhm[0] != nhm[1]):
+            raise ValueError("cross-modal attention needs the same head count and size in both streams (sub-layer %d: %d x %d vs %d x %d)"
+                             % (n, nhm[0], dh[0], nhm[1], dh[1]))
+        qkv = {m: self.buf(tag + "qkv%d" % m, (self.st[m].M, 3 * Ha[m])) for m in ms}
+        ctx = {m: self.buf(tag + "ctx%d" % m, (self.st[m].M, Ha[m])) for m in ms}
+        lse = {m: self.buf(tag + "lse%d" % m, (B * nhm[m] * self.st[m].L,), torch.float32) for m in ms}
+        d = {m: self.buf(tag + "z%d" % m, (self.st[m].M, Hm[m])) for m in ms}
+        y = {m: self.buf(tag + "y%d" % m, (self.st[m].M, Hm[m])) for m in ms}
         mean = {m: self.buf(tag + "mean%d" % m, (self.st[m].M,), torch.float32) for m in ms}
         rstd = {m: self.buf(tag + "rstd%d" % m, (self.st[m].M,), torch.float32) for m in ms}
 
         def wqkv(m, which):
             nm = names[m]
-            return self.arena.span([nm["q"] + ".weight", nm["k"] + ".weight", nm["v"] + ".weight"], which, (3 * H, H))
+            return self.arena.span([nm["q"] + ".weight", nm["k"] + ".weight", nm["v"] + ".weight"], which, (3 * Ha[m], Hm[m]))
 
         def bqkv(m, which):
             nm = names[m]
-            return self.arena.span([nm["q"] + ".bias", nm["k"] + ".bias", nm["v"] + ".bias"], which, (3 * H,))
+            return self.arena.span([nm["q"] + ".bias", nm["k"] + ".bias", nm["v"] + ".bias"], which, (3 * Ha[m],))
 
         if self.fp8:
             self.gemm_fp8(f, L.EPI_BF16, [(x8_in[m] or x_in[m], wqkv(m, "master"), qkv[m], bqkv(m, "master"), None) for m in ms])
         else:
-            self.gemm(f, L.NT, L.EPI_BF16, [self.prob(x_in[m], wqkv(m, "shadow"), qkv[m], self.st[m].M, 3 * H, H, H, H, 3 * H, bias=bqkv(m, "master")) for m in ms])
-        aa = L.AttnArgs()
-        for m in ms:
-            base = qkv[m].data_ptr()
-            aa.q[m], aa.k[m], aa.v[m] = base, base + 2 * H, base + 4 * H
-            aa.ld[m], aa.L[m] = 3 * H, self.st[m].L
-            aa.mask[m] = self.masks[m].data_ptr()
-            aa.ctx[m], aa.ldo[m], aa.lse[m] = ctx[m].data_ptr(), H, lse[m].data_ptr()
-        aa.B, aa.nh, aa.scale = B, nh, 1.0 / math.sqrt(64.0)
+            self.gemm(f, L.NT, L.EPI_BF16, [self.prob(x_in[m], wqkv(m, "shadow"), qkv[m], self.st[m].M, 3 * Ha[m], Hm[m], Hm[m], Hm[m], 3 * Ha[m], bias=bqkv(m, "master")) for m in ms])
         # dropout sites in the reference's call order: tt, tv, then vv, vt (encoders.py:294-295, 309-310)
         drops = {}
         if gate[0][0]:
@@ -857,21 +872,40 @@ class StepEngine:
             drops[(1, 1)] = self.drop(cfg.v_attention_probs_dropout_prob)
         if gate[1][0]:
             drops[(1, 0)] = self.drop(cfg.v_attention_probs_dropout_prob)
-        for i in range(2):
-            for j in range(2):
-                aa.gate[i][j] = gate[i][j]
-                aa.drop[i][j] = drops.get((i, j), L.dropout_cfg(None, 0, 0.0))
-        self.k(aa)
-        f.append((L.OP_ATTN_FWD, 0, 0, 0, aa, None, None))
-        self.gemm(f, L.NT, L.EPI_BF16, [self.prob(ctx[m], self.W(names[m]["o"] + ".weight"), d[m], self.st[m].M, H, H, H, H, H, bias=self.Pm(names[m]["o"] + ".bias")) for m in ms])
+        # one launch covers every gate block when the active streams share head count and size (every ctrl_* config, and the co-attention
+        # sub-layers of vilbert_base); two self-attentions with different heads (vilbert_base: 12 x 64 text, 8 x 128 vision) are two launches
+        if len(ms) == 2 and not cross and (nhm[0], dh[0]) != (nhm[1], dh[1]):
+            launches = [[[gate[0][0], 0], [0, 0]], [[0, 0], [0, gate[1][1]]]]
+        else:
+            launches = [gate]
+        attn = []
+        for gl in launches:
+            mq = [m for m in range(2) if gl[m][0] or gl[m][1] or gl[0][m] or gl[1][m]]
+            aa = L.AttnArgs()
+            for m in mq:
+                base = qkv[m].data_ptr()
+                aa.q[m], aa.k[m], aa.v[m] = base, base + 2 * Ha[m], base + 4 * Ha[m]
+                aa.ld[m], aa.L[m] = 3 * Ha[m], self.st[m].L
+                aa.mask[m] = self.masks[m].data_ptr()
+                aa.ctx[m], aa.ldo[m], aa.lse[m] = ctx[m].data_ptr(), Ha[m], lse[m].data_ptr()
+            m0 = mq[0]
+            aa.B, aa.nh, aa.scale, aa.dh = B, nhm[m0], 1.0 / math.sqrt(float(dh[m0])), dh[m0]
+            for i in range(2):
+                for j in range(2):
+                    aa.gate[i][j] = gl[i][j]
+                    aa.drop[i][j] = drops.get((i, j), L.dropout_cfg(None, 0, 0.0)) if gl[i][j] else L.dropout_cfg(None, 0, 0.0)
+            self.k(aa)
+            f.append((L.OP_ATTN_FWD, 0, 0, 0, aa, None, None))
+            attn.append((aa, mq, gl))
+        self.gemm(f, L.NT, L.EPI_BF16, [self.prob(ctx[m], self.W(names[m]["o"] + ".weight"), d[m], self.st[m].M, Hm[m], Ha[m], Ha[m], Ha[m], Hm[m], bias=self.Pm(names[m]["o"] + ".bias")) for m in ms])
         odrop, lnf = {}, []
         for m in ms:
             odrop[m] = self.drop(cfg.hidden_dropout_prob if m == 0 else cfg.v_hidden_dropout_prob)
             self.x8[m] = self.fp8_hidden(m) if self.fp8 else None
             lnf.append(self.ln_args(d[m], x_in[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", y[m], d[m], mean[m], rstd[m], self.st[m].M, odrop[m],
-                                    fp8_out=self.x8[m]))
+                                    fp8_out=self.x8[m], H=Hm[m]))
             self.x[m] = y[m]
-        f.append((L.OP_LN_FWD, 0, 0, 0, lnf[0], lnf[1] if len(lnf) > 1 else None, None))      # both streams in one launch
+        self._ln_pair(f, L.OP_LN_FWD, lnf)                     # both streams in one launch when their widths agree
         # ------------- backward
         b = []
         dz, dd, dctx, dqkv, dxn, dxi = {}, {}, {}, {}, {}, {}
@@ -880,42 +914,62 @@ class StepEngine:
             dxi[m], dxn[m] = self._dx_step(m)
             acc = 1 if (shared and i > 0) else 0
             par = self.sub_k % 2
-            dz[m] = self.tmp("dz%d_%d" % (m, par), (self.st[m].M, H))
-            dd[m] = self.tmp("dd%d_%d" % (m, par), (self.st[m].M, H)) if self.train else dz[m]
+            dz[m] = self.tmp("dz%d_%d" % (m, par), (self.st[m].M, Hm[m]))
+            dd[m] = self.tmp("dd%d_%d" % (m, par), (self.st[m].M, Hm[m])) if self.train else dz[m]
             lnb.append(self.ln_bwd_args(dxi[m], d[m], mean[m], rstd[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", dz[m],
-                                        dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc, defer=True))
-            dctx[m] = self.tmp("dctx%d" % m, (self.st[m].M, H))
-            dqkv[m] = self.tmp("dqkv%d_%d" % (m, par), (self.st[m].M, 3 * H))
-        b.append((L.OP_LN_BWD, 0, 0, 0, lnb[0], lnb[1] if len(lnb) > 1 else None, None))
-        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dd[m], self.W(names[m]["o"] + ".weight"), dctx[m], self.st[m].M, H, H, H, H, H) for m in ms])
-        ab = L.AttnBwdArgs()
+                                        dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc, defer=True, H=Hm[m]))
+            wtag = "" if Ha[m] == Hm[m] == self.H else "_%d" % Ha[m]      # temporaries are shared by name: other widths get their own
+            dctx[m] = self.tmp("dctx%d%s" % (m, wtag), (self.st[m].M, Ha[m]))
+            dqkv[m] = self.tmp("dqkv%d_%d%s" % (m, par, wtag), (self.st[m].M, 3 * Ha[m]))
+        self._ln_pair(b, L.OP_LN_BWD, lnb)
+        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dd[m], self.W(names[m]["o"] + ".weight"), dctx[m], self.st[m].M, Ha[m], Hm[m], Hm[m], Ha[m], Ha[m]) for m in ms])
         for m in ms:
             if not (gate[0][m] or gate[1][m]):       # K/V of this modality unused: their gradient is zero
                 b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MEMSET, p=(dqkv[m],), n=(dqkv[m].numel() * 2, 0)), None, None))
-            ab.dctx[m] = dctx[m].data_ptr()
-            base = dqkv[m].data_ptr()
-            ab.dq[m], ab.dk[m], ab.dv[m], ab.ldg[m] = base, base + 2 * H, base + 4 * H, 3 * H
-        self.k(ab)
-        b.append((L.OP_ATTN_BWD, 0, 0, 0, aa, ab, None))
-        self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dqkv[m], wqkv(m, "shadow"), dxn[m], self.st[m].M, H, 3 * H, 3 * H, H, H, R=dz[m], ldr=H) for m in ms])
+        for aa, mq, gl in attn:
+            ab = L.AttnBwdArgs()
+            for m in mq:
+                ab.dctx[m] = dctx[m].data_ptr()
+                base = dqkv[m].data_ptr()
+                ab.dq[m], ab.dk[m], ab.dv[m], ab.ldg[m] = base, base + 2 * Ha[m], base + 4 * Ha[m], 3 * Ha[m]
+            self.k(ab)
+            b.append((L.OP_ATTN_BWD, 0, 0, 0, aa, ab, None))
+        self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dqkv[m], wqkv(m, "shadow"), dxn[m], self.st[m].M, Hm[m], 3 * Ha[m], 3 * Ha[m], Hm[m], Hm[m], R=dz[m], ldr=Hm[m]) for m in ms])
         # all weight gradients of the sub-layer in ONE grouped launch (more workgroups per CU)
-        self._wgrad(b, ms, shared, [lambda m: (dd[m], ctx[m], self.G(names[m]["o"] + ".weight"), self.G(names[m]["o"] + ".bias"), H, H, H, H),
-                                    lambda m: (dqkv[m], x_in[m], wqkv(m, "grad"), bqkv(m, "grad"), 3 * H, H, 3 * H, H)])
+        self._wgrad(b, ms, shared, [lambda m: (dd[m], ctx[m], self.G(names[m]["o"] + ".weight"), self.G(names[m]["o"] + ".bias"), Hm[m], Ha[m], Hm[m], Ha[m]),
+                                    lambda m: (dqkv[m], x_in[m], wqkv(m, "grad"), bqkv(m, "grad"), 3 * Ha[m], Hm[m], 3 * Ha[m], Hm[m])])
         return b
 
+    def _ln_pair(self, ops, kind, jobs):
+        """One LayerNorm launch for both streams when their widths agree (the kernels share the launch between two jobs of equal width),
+        one launch per stream otherwise."""
+        if len(jobs) == 2 and jobs[0].H == jobs[1].H:
+            ops.append((kind, 0, 0, 0, jobs[0], jobs[1], None))
+        else:
+            for j in jobs:
+                ops.append((kind, 0, 0, 0, j, None, None))
+
     def _ffn_sublayer(self, n):
-        cfg, H, I = self.cfg, self.H, self.I
+        cfg = self.cfg
         f = self.fwd.ops
+        # per-stream widths: hidden Hm, intermediate Im (config/vilbert_base.json: 768 / 3072 text, 1024 / 1024 vision; encoders.py:459-460,514-515)
+        Hm = [self.st[0].H, self.st[1].H]
+        Im = [cfg.sublayer2intermediate_size.get(str(n), cfg.intermediate_size), cfg.sublayer2v_intermediate_size.get(str(n), cfg.v_intermediate_size)]
+        for m in range(2):
+            if Im[m] % 64:
+                raise NotImplementedError("intermediate sizes must be multiples of 64")
         act = [n in cfg.t_ff_sublayers, n in cfg.v_ff_sublayers]
         names, shared = self._names(n, "ff")
         ms = [m for m in range(2) if act[m]]
         tag = "L%d_" % n
         x_in = list(self.x)
         x8_in = list(self.x8)
-        h = {m: self.buf(tag + "h%d" % m, (self.st[m].M, I)) for m in ms}
-        gp = {m: self.buf(tag + "gp%d" % m, (self.st[m].M, I)) for m in ms}
-        d = {m: self.buf(tag + "z%d" % m, (self.st[m].M, H)) for m in ms}
-        y = {m: self.buf(tag + "y%d" % m, (self.st[m].M, H)) for m in ms}
+        if shared and len(ms) == 2 and (Hm[0] != Hm[1] or Im[0] != Im[1]):
+            raise ValueError("a shared feed-forward sub-layer needs equal widths in both streams")
+        h = {m: self.buf(tag + "h%d" % m, (self.st[m].M, Im[m])) for m in ms}
+        gp = {m: self.buf(tag + "gp%d" % m, (self.st[m].M, Im[m])) for m in ms}
+        d = {m: self.buf(tag + "z%d" % m, (self.st[m].M, Hm[m])) for m in ms}
+        y = {m: self.buf(tag + "y%d" % m, (self.st[m].M, Hm[m])) for m in ms}
         mean = {m: self.buf(tag + "mean%d" % m, (self.st[m].M,), torch.float32) for m in ms}
         rstd = {m: self.buf(tag + "rstd%d" % m, (self.st[m].M,), torch.float32) for m in ms}
         if self.fp8:
@@ -924,7 +978,7 @@ class StepEngine:
             up, specs = [], []
             for m in ms:
                 Mm = self.st[m].M
-                h8 = self.tmp("fp8_h%d_%d" % (m, Mm), (Mm, I), torch.uint8)
+                h8 = self.tmp("fp8_h%d_%d" % (m, Mm), (Mm, Im[m]), torch.uint8)
                 if "fp8_hscale_%d" % Mm not in self.bufs:
                     self.bufs["fp8_hscale_%d" % Mm] = torch.full((Mm,), 1.0 / self.H8_MUL, dtype=torch.float32, device=self.dev)
                 up.append((x8_in[m] or x_in[m], self.Pm(names[m]["up"] + ".weight"), h[m], self.Pm(names[m]["up"] + ".bias"), gp[m], (h8, self.H8_MUL)))
@@ -932,16 +986,16 @@ class StepEngine:
             self.gemm_fp8(f, L.EPI_GELU, up)
             self.gemm_fp8(f, L.EPI_BF16, specs)
         else:
-            self.gemm(f, L.NT, L.EPI_GELU, [self.prob(x_in[m], self.W(names[m]["up"] + ".weight"), h[m], self.st[m].M, I, H, H, H, I, bias=self.Pm(names[m]["up"] + ".bias"), C2=gp[m]) for m in ms])
-            self.gemm(f, L.NT, L.EPI_BF16, [self.prob(h[m], self.W(names[m]["down"] + ".weight"), d[m], self.st[m].M, H, I, I, I, H, bias=self.Pm(names[m]["down"] + ".bias")) for m in ms])
+            self.gemm(f, L.NT, L.EPI_GELU, [self.prob(x_in[m], self.W(names[m]["up"] + ".weight"), h[m], self.st[m].M, Im[m], Hm[m], Hm[m], Hm[m], Im[m], bias=self.Pm(names[m]["up"] + ".bias"), C2=gp[m]) for m in ms])
+            self.gemm(f, L.NT, L.EPI_BF16, [self.prob(h[m], self.W(names[m]["down"] + ".weight"), d[m], self.st[m].M, Hm[m], Im[m], Im[m], Im[m], Hm[m], bias=self.Pm(names[m]["down"] + ".bias")) for m in ms])
         odrop, lnf = {}, []
         for m in ms:
             odrop[m] = self.drop(cfg.hidden_dropout_prob if m == 0 else cfg.v_hidden_dropout_prob)
             self.x8[m] = self.fp8_hidden(m) if self.fp8 else None
             lnf.append(self.ln_args(d[m], x_in[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", y[m], d[m], mean[m], rstd[m], self.st[m].M, odrop[m],
-                                    fp8_out=self.x8[m]))
+                                    fp8_out=self.x8[m], H=Hm[m]))
             self.x[m] = y[m]
-        f.append((L.OP_LN_FWD, 0, 0, 0, lnf[0], lnf[1] if len(lnf) > 1 else None, None))      # both streams in one launch
+        self._ln_pair(f, L.OP_LN_FWD, lnf)                     # both streams in one launch when their widths agree
         b = []
         dz, dd, du, dxn, dxi = {}, {}, {}, {}, {}
         lnb = []
@@ -949,16 +1003,17 @@ class StepEngine:
             dxi[m], dxn[m] = self._dx_step(m)
             acc = 1 if (shared and i > 0) else 0
             par = self.sub_k % 2
-            dz[m] = self.tmp("dz%d_%d" % (m, par), (self.st[m].M, H))
-            dd[m] = self.tmp("dd%d_%d" % (m, par), (self.st[m].M, H)) if self.train else dz[m]
+            dz[m] = self.tmp("dz%d_%d" % (m, par), (self.st[m].M, Hm[m]))
+            dd[m] = self.tmp("dd%d_%d" % (m, par), (self.st[m].M, Hm[m])) if self.train else dz[m]
             lnb.append(self.ln_bwd_args(dxi[m], d[m], mean[m], rstd[m], names[m]["ln"] + ".weight", names[m]["ln"] + ".bias", dz[m],
-                                        dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc, defer=True))
-            du[m] = self.tmp("du%d_%d" % (m, par), (self.st[m].M, I))
-        b.append((L.OP_LN_BWD, 0, 0, 0, lnb[0], lnb[1] if len(lnb) > 1 else None, None))
-        self.gemm(b, L.NN, L.EPI_MULR, [self.prob(dd[m], self.W(names[m]["down"] + ".weight"), du[m], self.st[m].M, I, H, H, I, I, R=gp[m], ldr=I) for m in ms])
-        self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(du[m], self.W(names[m]["up"] + ".weight"), dxn[m], self.st[m].M, H, I, I, H, H, R=dz[m], ldr=H) for m in ms])
-        self._wgrad(b, ms, shared, [lambda m: (dd[m], h[m], self.G(names[m]["down"] + ".weight"), self.G(names[m]["down"] + ".bias"), H, I, H, I),
-                                    lambda m: (du[m], x_in[m], self.G(names[m]["up"] + ".weight"), self.G(names[m]["up"] + ".bias"), I, H, I, H)])
+                                        dd[m] if self.train else None, self.st[m].M, odrop[m], accumulate=acc, defer=True, H=Hm[m]))
+            wtag = "" if Im[m] == self.I else "_%d" % Im[m]               # temporaries are shared by name: other widths get their own
+            du[m] = self.tmp("du%d_%d%s" % (m, par, wtag), (self.st[m].M, Im[m]))
+        self._ln_pair(b, L.OP_LN_BWD, lnb)
+        self.gemm(b, L.NN, L.EPI_MULR, [self.prob(dd[m], self.W(names[m]["down"] + ".weight"), du[m], self.st[m].M, Im[m], Hm[m], Hm[m], Im[m], Im[m], R=gp[m], ldr=Im[m]) for m in ms])
+        self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(du[m], self.W(names[m]["up"] + ".weight"), dxn[m], self.st[m].M, Hm[m], Im[m], Im[m], Hm[m], Hm[m], R=dz[m], ldr=Hm[m]) for m in ms])
+        self._wgrad(b, ms, shared, [lambda m: (dd[m], h[m], self.G(names[m]["down"] + ".weight"), self.G(names[m]["down"] + ".bias"), Hm[m], Im[m], Hm[m], Im[m]),
+                                    lambda m: (du[m], x_in[m], self.G(names[m]["up"] + ".weight"), self.G(names[m]["up"] + ".bias"), Im[m], Hm[m], Im[m], Hm[m])])
         return b
 
     def _wgrad(self, b, ms, shared, specs):
@@ -1040,6 +1095,7 @@ class StepEngine:
     # ---------------------------------------------------------------- heads + losses
     def _heads(self):
         cfg, B, H, T, Rv, R = self.cfg, self.B, self.H, self.T, self.Rv, self.R
+        Hv = self.st[1].H                               # the vision stream's width (config/vilbert_base.json: 1024 against 768)
         f = self.fwd.ops
         st_t, st_v = self.st
         fm = cfg.fusion_method
@@ -1068,7 +1124,7 @@ class StepEngine:
             pools = [self.prob(x_t, self.W("bert.t_pooler.dense.weight"), pt, B, P, H, T * H, H, P, bias=self.Pm("bert.t_pooler.dense.bias"))]
             if fm != "text":
                 pv = self.buf("pooled_v", (B, P))
-                pools.append(self.prob(x_v, self.W("bert.v_pooler.dense.weight"), pv, B, P, H, Rv * H, H, P, bias=self.Pm("bert.v_pooler.dense.bias")))
+                pools.append(self.prob(x_v, self.W("bert.v_pooler.dense.weight"), pv, B, P, Hv, Rv * Hv, Hv, P, bias=self.Pm("bert.v_pooler.dense.bias")))
             self.gemm(f, L.NT, L.EPI_RELU, pools)
         elif fm == "vl-bert_vqa":
             pt = self._vqa_text_pooler(f, x_t)[0]               # BertModel's fourth output; nothing in the pre-training loss reads it
@@ -1102,15 +1158,15 @@ class StepEngine:
         g = self.generic(L.FN_SELECT, p=(None, rows_v, pos_v, n_v), n=(Mr, 1, R, Rv, off))
         self.patch("image_label", g, "p", 0)
         f.append((L.OP_GENERIC, 0, 0, 0, g, None, None))
-        hx_v = self.buf("img_hx", (Mr, H))
-        f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_GATHER, p=(x_v, rows_v, n_v, hx_v), n=(H, Mr)), None, None))
+        hx_v = self.buf("img_hx", (Mr, Hv))
+        f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_GATHER, p=(x_v, rows_v, n_v, hx_v), n=(Hv, Mr)), None, None))
         ci = "cls.imagePredictions."
-        hv, gpv = self.buf("img_ht", (Mr, H)), self.buf("img_gp", (Mr, H))
-        self.gemm(f, L.NT, L.EPI_GELU, [self.prob(hx_v, self.W(ci + "transform.dense.weight"), hv, Mr, H, H, H, H, H, bias=self.Pm(ci + "transform.dense.bias"), C2=gpv, dyn=n_v)])
+        hv, gpv = self.buf("img_ht", (Mr, Hv)), self.buf("img_gp", (Mr, Hv))
+        self.gemm(f, L.NT, L.EPI_GELU, [self.prob(hx_v, self.W(ci + "transform.dense.weight"), hv, Mr, Hv, Hv, Hv, Hv, Hv, bias=self.Pm(ci + "transform.dense.bias"), C2=gpv, dyn=n_v)])
         if cfg.image_head_ln:
-            hn_v = self.buf("img_hn", (Mr, H))
+            hn_v = self.buf("img_hn", (Mr, Hv))
             im_mean, im_rstd = self.buf("img_mean", (Mr,), torch.float32), self.buf("img_rstd", (Mr,), torch.float32)
-            f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(hv, None, ci + "transform.LayerNorm.weight", ci + "transform.LayerNorm.bias", hn_v, None, im_mean, im_rstd, Mr, nodrop, dyn=n_v), None, None))
+            f.append((L.OP_LN_FWD, 0, 0, 0, self.ln_args(hv, None, ci + "transform.LayerNorm.weight", ci + "transform.LayerNorm.bias", hn_v, None, im_mean, im_rstd, Mr, nodrop, dyn=n_v, H=Hv), None, None))
         else:
             hn_v = hv
         # one decoder + loss per configured visual target (encoders.py:718-737,1079-1087; losses.py); all of them add their WEIGHTED row
@@ -1122,7 +1178,7 @@ class StepEngine:
             tag = "img" if ix == "0" else "img%s" % ix
             logits_v = self.buf(tag + "_logits", (Mr, Cp), torch.float32)
             wdec = ci + "decoder_dict.%s." % ix
-            self.gemm(f, L.NT, L.EPI_F32, [self.prob(hn_v, self.W(wdec + "weight"), logits_v, Mr, Cn, H, H, H, Cp, bias=self.Pm(wdec + "bias"), dyn=n_v, n_store=Cp)])
+            self.gemm(f, L.NT, L.EPI_F32, [self.prob(hn_v, self.W(wdec + "weight"), logits_v, Mr, Cn, Hv, Hv, Hv, Cp, bias=self.Pm(wdec + "bias"), dyn=n_v, n_store=Cp)])
             lse_v = self.buf(tag + "_lse", (Mr,), torch.float32)
             if ix == "0":
                 tsum_v = self.buf("img_tsum", (Mr,), torch.float32)
@@ -1178,7 +1234,7 @@ class StepEngine:
             b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MEMSET, p=(dxh[m],), n=(dxh[m].numel() * 2, 0)), None, None))
         # ---- region chain (side stream)
         b.append((L.OP_SIDE_BEGIN, 0, 0, 0, None, None, None))
-        dhn_v = self.tmp("head_v_d1", (Mr, H))
+        dhn_v = self.tmp("head_v_d1", (Mr, Hv))
         for j, (ix, Cn, Cp, la, tag) in enumerate(vis):
             dlog_v = self.buf(tag + "_dlogits", (Mr, Cp))
             if ix == "0":
@@ -1187,21 +1243,21 @@ class StepEngine:
                 b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_VIS_LOSS_BWD, p=(la, dlog_v, self.gout[1:2]), n=(Cp,)), None, None))
             wdec = ci + "decoder_dict.%s." % ix
             if j == 0:
-                self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dlog_v, self.W(wdec + "weight"), dhn_v, Mr, H, Cn, Cp, H, H, dyn=n_v)])
+                self.gemm(b, L.NN, L.EPI_BF16, [self.prob(dlog_v, self.W(wdec + "weight"), dhn_v, Mr, Hv, Cn, Cp, Hv, Hv, dyn=n_v)])
             else:                                               # the decoders share the transformed hidden state: their input gradients add up
-                self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dlog_v, self.W(wdec + "weight"), dhn_v, Mr, H, Cn, Cp, H, H, dyn=n_v, R=dhn_v, ldr=H)])
-            self.gemm(b, L.TN, L.EPI_F32, [self.prob(dlog_v, hn_v, self.G(wdec + "weight"), Cn, H, Mr, Cp, H, H, bias_grad=self.G(wdec + "bias"), dyn=n_v)])
+                self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dlog_v, self.W(wdec + "weight"), dhn_v, Mr, Hv, Cn, Cp, Hv, Hv, dyn=n_v, R=dhn_v, ldr=Hv)])
+            self.gemm(b, L.TN, L.EPI_F32, [self.prob(dlog_v, hn_v, self.G(wdec + "weight"), Cn, Hv, Mr, Cp, Hv, Hv, bias_grad=self.G(wdec + "bias"), dyn=n_v)])
         if cfg.image_head_ln:
-            dhv = self.tmp("head_v_d2", (Mr, H))
-            b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dhn_v, hv, im_mean, im_rstd, ci + "transform.LayerNorm.weight", ci + "transform.LayerNorm.bias", dhv, None, Mr, nodrop, dyn=n_v, own_partial=True), None, None))
+            dhv = self.tmp("head_v_d2", (Mr, Hv))
+            b.append((L.OP_LN_BWD, 0, 0, 0, self.ln_bwd_args(dhn_v, hv, im_mean, im_rstd, ci + "transform.LayerNorm.weight", ci + "transform.LayerNorm.bias", dhv, None, Mr, nodrop, dyn=n_v, own_partial=True, H=Hv), None, None))
         else:
             dhv = dhn_v
-        du_v = self.tmp("head_v_d3", (Mr, H))
-        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MUL, p=(dhv, gpv, du_v, n_v), n=(Mr * H, H)), None, None))
-        dhx_v = self.tmp("head_v_d2" if not cfg.image_head_ln else "head_v_d1", (Mr, H))
-        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(du_v, self.W(ci + "transform.dense.weight"), dhx_v, Mr, H, H, H, H, H, dyn=n_v)])
-        self.gemm(b, L.TN, L.EPI_F32, [self.prob(du_v, hx_v, self.G(ci + "transform.dense.weight"), H, H, Mr, H, H, H, bias_grad=self.G(ci + "transform.dense.bias"), dyn=n_v)])
-        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SCATTER_ADD, p=(dhx_v, rows_v, n_v, dxh[1]), n=(H, Mr)), None, None))
+        du_v = self.tmp("head_v_d3", (Mr, Hv))
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MUL, p=(dhv, gpv, du_v, n_v), n=(Mr * Hv, Hv)), None, None))
+        dhx_v = self.tmp("head_v_d2" if not cfg.image_head_ln else "head_v_d1", (Mr, Hv))
+        self.gemm(b, L.NN, L.EPI_BF16, [self.prob(du_v, self.W(ci + "transform.dense.weight"), dhx_v, Mr, Hv, Hv, Hv, Hv, Hv, dyn=n_v)])
+        self.gemm(b, L.TN, L.EPI_F32, [self.prob(du_v, hx_v, self.G(ci + "transform.dense.weight"), Hv, Hv, Mr, Hv, Hv, Hv, bias_grad=self.G(ci + "transform.dense.bias"), dyn=n_v)])
+        b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SCATTER_ADD, p=(dhx_v, rows_v, n_v, dxh[1]), n=(Hv, Mr)), None, None))
         b.append((L.OP_SIDE_END, 13, 0, 0, None, None, None))
         # ---- masked-LM chain
         dlog_t = self.buf("lm_dlogits", (st_t.M, Vp))
@@ -1248,8 +1304,9 @@ class StepEngine:
             poolers = [(0, dyt, x_t, T, "bert.t_pooler.dense.")] + ([(1, dyv, x_v, Rv, "bert.v_pooler.dense.")] if pv is not None else [])
         for m, dy_, xm, Lm, pre in poolers:
             # rows b * L: the first token of every sample -- disjoint from the labelled rows the region chain scatters into
-            self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dy_, self.W(pre + "weight"), dxh[m], B, H, P, P, H, Lm * H, R=dxh[m], ldr=Lm * H)])
-            self.gemm(wg, L.TN, L.EPI_F32, [self.prob(dy_, xm, self.G(pre + "weight"), P, H, B, P, Lm * H, H, bias_grad=self.G(pre + "bias"))])
+            Hm = self.st[m].H
+            self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dy_, self.W(pre + "weight"), dxh[m], B, Hm, P, P, Hm, Lm * Hm, R=dxh[m], ldr=Lm * Hm)])
+            self.gemm(wg, L.TN, L.EPI_F32, [self.prob(dy_, xm, self.G(pre + "weight"), P, Hm, B, P, Lm * Hm, Hm, bias_grad=self.G(pre + "bias"))])
         # ---- the main chains' weight gradients, off the critical path
         b.append((L.OP_SIDE_BEGIN, 0, 0, 0, None, None, None))
         b += wg
@@ -1290,6 +1347,7 @@ class StepEngine:
             raise NotImplementedError("pooler sizes must match and be multiples of 64")
         x_t, x_v = self.x
         st_v = self.st[1]
+        Hv = st_v.H
         pt = pv = None
         vqa = None
         if fm == "vl-bert_vqa":
@@ -1299,7 +1357,7 @@ class StepEngine:
             pools = [self.prob(x_t, self.W("bert.t_pooler.dense.weight"), pt, B, P, H, T * H, H, P, bias=self.Pm("bert.t_pooler.dense.bias"))]
             if fm != "text":
                 pv = self.buf("pooled_v", (B, P))
-                pools.append(self.prob(x_v, self.W("bert.v_pooler.dense.weight"), pv, B, P, H, Rv * H, H, P, bias=self.Pm("bert.v_pooler.dense.bias")))
+                pools.append(self.prob(x_v, self.W("bert.v_pooler.dense.weight"), pv, B, P, Hv, Rv * Hv, Hv, P, bias=self.Pm("bert.v_pooler.dense.bias")))
             self.gemm(f, L.NT, L.EPI_RELU, pools)
         self.taps.update(seq_t=x_t, seq_v=x_v, pooled_t=pt, pooled_v=pv)
         # The word-embedding gradient is accumulated with atomics by the embedding backward; in the pre-training model the LM
@@ -1335,26 +1393,26 @@ class StepEngine:
             if typ.startswith("V-logit"):
                 Mv = st_v.M
                 d0 = self.drop(0.1)                          # BertForVLTasks.dropout on the region states (:1198)
-                xd = self.buf("task_xd", (Mv, H))
-                f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ADD_DROPOUT, p=(x_v, None, xd), n=(Mv, H, 0), f=(1.0,), drop=d0), None, None))
+                xd = self.buf("task_xd", (Mv, Hv))
+                f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ADD_DROPOUT, p=(x_v, None, xd), n=(Mv, Hv, 0), f=(1.0,), drop=d0), None, None))
                 if tcfg.get("num_clf_layers", 1) == 2:       # Linear -> GELU -> Dropout -> Linear (:1138-1144)
-                    h, gp = self.buf("task_h", (Mv, H)), self.buf("task_gp", (Mv, H))
-                    self.gemm(f, L.NT, L.EPI_GELU, [self.prob(xd, self.W(pre + "0.weight"), h, Mv, H, H, H, H, H, bias=self.Pm(pre + "0.bias"), C2=gp)])
+                    h, gp = self.buf("task_h", (Mv, Hv)), self.buf("task_gp", (Mv, Hv))
+                    self.gemm(f, L.NT, L.EPI_GELU, [self.prob(xd, self.W(pre + "0.weight"), h, Mv, Hv, Hv, Hv, Hv, Hv, bias=self.Pm(pre + "0.bias"), C2=gp)])
                     d1 = self.drop(cfg.v_attention_probs_dropout_prob)
-                    hd = self.buf("task_hd", (Mv, H))
-                    f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ADD_DROPOUT, p=(h, None, hd), n=(Mv, H, 0), f=(1.0,), drop=d1), None, None))
-                    self.pred, self.d_pred, Cp = linear_out(hd, Mv, H, pre + "3.", 1)
-                    dhd, dh, du = self.buf("task_dhd", (Mv, H)), self.buf("task_dh", (Mv, H)), self.buf("task_du", (Mv, H))
-                    linear_bwd(self.d_pred, Cp, hd, Mv, H, pre + "3.", 1, dhd)
-                    b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ADD_DROPOUT, p=(dhd, None, dh), n=(Mv, H, 1), f=(1.0,), drop=d1), None, None))
-                    b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MUL, p=(dh, gp, du, None), n=(Mv * H, H)), None, None))
-                    dxd = self.buf("task_dxd", (Mv, H))
-                    linear_bwd(du, H, xd, Mv, H, pre + "0.", H, dxd)
+                    hd = self.buf("task_hd", (Mv, Hv))
+                    f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ADD_DROPOUT, p=(h, None, hd), n=(Mv, Hv, 0), f=(1.0,), drop=d1), None, None))
+                    self.pred, self.d_pred, Cp = linear_out(hd, Mv, Hv, pre + "3.", 1)
+                    dhd, dh, du = self.buf("task_dhd", (Mv, Hv)), self.buf("task_dh", (Mv, Hv)), self.buf("task_du", (Mv, Hv))
+                    linear_bwd(self.d_pred, Cp, hd, Mv, Hv, pre + "3.", 1, dhd)
+                    b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ADD_DROPOUT, p=(dhd, None, dh), n=(Mv, Hv, 1), f=(1.0,), drop=d1), None, None))
+                    b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_MUL, p=(dh, gp, du, None), n=(Mv * Hv, Hv)), None, None))
+                    dxd = self.buf("task_dxd", (Mv, Hv))
+                    linear_bwd(du, Hv, xd, Mv, Hv, pre + "0.", Hv, dxd)
                 else:
-                    self.pred, self.d_pred, Cp = linear_out(xd, Mv, H, pre, 1)
-                    dxd = self.buf("task_dxd", (Mv, H))
-                    linear_bwd(self.d_pred, Cp, xd, Mv, H, pre, 1, dxd)
-                b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ADD_DROPOUT, p=(dxd, None, dxh[1]), n=(Mv, H, 1), f=(1.0,), drop=d0), None, None))
+                    self.pred, self.d_pred, Cp = linear_out(xd, Mv, Hv, pre, 1)
+                    dxd = self.buf("task_dxd", (Mv, Hv))
+                    linear_bwd(self.d_pred, Cp, xd, Mv, Hv, pre, 1, dxd)
+                b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ADD_DROPOUT, p=(dxd, None, dxh[1]), n=(Mv, Hv, 1), f=(1.0,), drop=d0), None, None))
                 self.pred_shape = (B, Rv, 1)
             else:
                 if fm == "none":
@@ -1411,8 +1469,9 @@ class StepEngine:
                 b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SCATTER_ADD, p=(dxg, vqa_rows, vqa_cnt, dxh[0]), n=(H, B)), None, None))
                 self.gemm(b, L.TN, L.EPI_F32, [self.prob(dy_, xg, self.G(pre_p + "weight"), P, H, B, P, H, H, bias_grad=self.G(pre_p + "bias"))])
             else:
-                self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dy_, self.W(pre_p + "weight"), dxh[m], B, H, P, P, H, Lm * H, R=dxh[m], ldr=Lm * H)])
-                self.gemm(b, L.TN, L.EPI_F32, [self.prob(dy_, xm, self.G(pre_p + "weight"), P, H, B, P, Lm * H, H, bias_grad=self.G(pre_p + "bias"))])
+                Hm = self.st[m].H
+                self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dy_, self.W(pre_p + "weight"), dxh[m], B, Hm, P, P, Hm, Lm * Hm, R=dxh[m], ldr=Lm * Hm)])
+                self.gemm(b, L.TN, L.EPI_F32, [self.prob(dy_, xm, self.G(pre_p + "weight"), P, Hm, B, P, Lm * Hm, Hm, bias_grad=self.G(pre_p + "bias"))])
         return b
 
     # ---------------------------------------------------------------- run

@@ -459,7 +459,7 @@ class BertForVLPreTraining(PreTrainedModel):
         eng = self._last[0]
         H = self.config.hidden_size
         pt, pv = eng.taps["pooled_t"], eng.taps["pooled_v"]          # None where the fusion method has no such pooler
-        return (eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, H).float(),
+        return (eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, self.config.v_hidden_size).float(),
                 None if pt is None else pt.float(), None if pv is None else pv.float(), ([], []))
 
 
@@ -575,7 +575,7 @@ class BertForVLTasks(PreTrainedModel):
         eng = self._last[0]
         H = self.config.hidden_size
         pt, pv = eng.taps["pooled_t"], eng.taps["pooled_v"]          # None where the fusion method has no such pooler
-        return (eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, H).float(),
+        return (eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, self.config.v_hidden_size).float(),
                 None if pt is None else pt.float(), None if pv is None else pv.float(), ([], []))
 
     def forward(self, input_txt, input_imgs, image_loc, task_id, token_type_ids=None, attention_mask=None,
