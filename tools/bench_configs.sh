@@ -14,3 +14,7 @@ run vlbert_b256 --config ctrl_vl-bert_base
 run vlbert_r100_b256 --config ctrl_vl-bert_base --regions 100
 run vlbert_r100_b256_fp8 --config ctrl_vl-bert_base --regions 100 --dtype fp8
 run uniter_b512_fp8 --config ctrl_uniter_base --batch 512 --dtype fp8
+# the reference's non-ctrl configurations: original-paper geometries and targets
+run vilbert_base_b256 --config vilbert_base
+run lxmert_orig_b256 --config lxmert
+run vlbert_orig_b256 --config vl-bert_base

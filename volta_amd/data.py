@@ -41,15 +41,19 @@ def synthetic_batch(config, batch_size, seq_len=20, num_regions=36, seed=1234, d
         image_label = torch.where(image_label == 0, torch.full_like(image_label, -1), image_label)
         lm = lm * keep
         lm = torch.where(lm == 0, torch.full_like(lm, -1), lm)
-    return dict(input_ids=ids, input_mask=input_mask, segment_ids=torch.zeros(B, T, dtype=torch.long, device=device),
-                lm_label_ids=lm, is_match=is_match, image_feat=feat.contiguous(), image_loc=loc.contiguous(), image_cls=cls,
-                image_label=image_label, image_mask=image_mask)
+    out = dict(input_ids=ids, input_mask=input_mask, segment_ids=torch.zeros(B, T, dtype=torch.long, device=device),
+               lm_label_ids=lm, is_match=is_match, image_feat=feat.contiguous(), image_loc=loc[..., :config.num_locs].contiguous(), image_cls=cls,
+               image_label=image_label, image_mask=image_mask)
+    if set(config.visual_target_weights) - {"0"}:          # detector outputs for the hard-label targets (volta/losses.py:83-124)
+        out.update(obj_labels=torch.randint(0, 1600, (B, R), **kw), obj_confs=torch.rand(B, R, **kw),
+                   attr_labels=torch.randint(0, 400, (B, R), **kw), attr_confs=torch.rand(B, R, **kw))
+    return out
 
 
 def model_args(b):
     """Positional arguments in the order of the reference driver's call (train_concap.py:286-289)."""
     return (b["input_ids"], b["image_feat"], b["image_loc"], b["segment_ids"], b["input_mask"], b["image_mask"], b["lm_label_ids"],
-            b["image_label"], b["image_cls"], None, None, None, None, None, b["is_match"])
+            b["image_label"], b["image_cls"], b.get("obj_labels"), b.get("obj_confs"), b.get("attr_labels"), b.get("attr_confs"), None, b["is_match"])
 
 
 class ConceptCapBatchProducer:
