@@ -228,3 +228,29 @@ def test_non_ctrl_config_matches_reference_fixture(golden_dir, name):
     total = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.grad is not None)))
     assert abs(total - float(z["out::grad_norm"][0])) / float(z["out::grad_norm"][0]) <= 1e-2, report
     print(name, {k: float("%.2e" % v) for k, v in report.items()})
+
+
+@pytest.mark.parametrize("name", ["lxmert_text", "sum_mse_kl", "vlbert_none"])
+def test_score_returning_branch(name):
+    """BertForVLPreTraining.forward without labels (volta/encoders.py:1113-1114): the heads' scores at every position against the oracle's
+    taps -- text scores, every visual target's scores, the ITM score where the fusion method has one, the fused pooled vector."""
+    cd = VARIANTS[name]
+    model, rcfg, sd = build(cd)
+    model.eval()
+    batch = R.synthetic_batch(rcfg, 3, 20, 36, seed=5, pad=True)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    st, sv, itm, maps, pooled = model(cb["input_ids"], cb["image_feat"], cb["image_loc"], cb["segment_ids"], cb["input_mask"], cb["image_mask"])
+    torch.cuda.synchronize()
+    taps = {}
+    with torch.no_grad():
+        R.forward_from_batch(sd, rcfg, batch, taps=taps)
+    assert rel_err(st.float().cpu(), taps["scores_t"]) <= 3e-2
+    assert set(sv) == set(taps["scores_v_dict"])
+    for ix, t in sv.items():
+        assert rel_err(t.float().cpu(), taps["scores_v_dict"][ix]) <= 3e-2, ix
+    if taps["itm"] is None:
+        assert itm is None
+    else:
+        assert rel_err(itm.float().cpu(), taps["itm"]) <= 5e-2
+    assert maps == ([], [])
+    assert (pooled is None) == (cd["fusion_method"] == "none")

@@ -430,9 +430,11 @@ class BertForVLPreTraining(PreTrainedModel):
                 output_all_attention_masks=False):
         if output_all_attention_masks:
             raise NotImplementedError("attention maps are never materialised by the fused attention kernel")
+        if masked_lm_labels is None and next_sentence_label is None:
+            # encoders.py:1113-1114: without text labels and without a masked region every loss is zero and the reference returns the heads' scores
+            return self._scores(input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask, image_label)
         if masked_lm_labels is None or image_label is None:
-            raise NotImplementedError("the pre-training step needs masked_lm_labels and image_label (the score-returning branch of "
-                                      "encoders.py:1113-1114 is reached only when every loss is zero and is not on the hot path)")
+            raise NotImplementedError("the pre-training step needs masked_lm_labels and image_label")
         tensors, B, T, Rv = self._prep_inputs(input_ids, image_feat, image_loc, token_type_ids, attention_mask,
                                               image_attention_mask, masked_lm_labels, image_label, image_cls, next_sentence_label,
                                               obj_labels, obj_confs, attr_labels, attr_confs)
@@ -442,6 +444,65 @@ class BertForVLPreTraining(PreTrainedModel):
             return _PretrainStep.apply(self, anchor, tensors)
         losses = self._engine_forward(tensors)
         return losses[0:1].clone(), losses[1:2].clone(), losses[2:3].clone()
+
+    def _scores(self, input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask, image_label):
+        """The score-returning branch of BertForVLPreTraining.forward (volta/encoders.py:1065-1068,1113-1114): (prediction_scores_t [B,T,V],
+        {target: prediction_scores_v [B,Rv,C]}, seq_relationship_score [B,2] or None, attention maps = ([], []), pooled_output or None), the heads
+        applied to EVERY position.  Inference only (no gradient, the heads' dropout is the identity); the projections run on the library's GEMM /
+        LayerNorm kernels through volta_amd.ops."""
+        from . import _lib as L, ops
+        if image_label is not None and bool((image_label == 1).any()):
+            raise ValueError("masked regions without text labels: the reference returns the losses here, which need masked_lm_labels")
+        with torch.no_grad():
+            was_training = self.training
+            self.eval()
+            try:
+                seq_t, seq_v, pt, pv, _ = self.encode(input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask)
+            finally:
+                self.train(was_training)
+            eng = self._last[0]
+            arena = eng.arena
+            W, Pm = (lambda n: arena.view(n, "shadow")), (lambda n: arena.view(n, "master"))
+            dev = seq_t.device
+            B, T, H = seq_t.shape
+            Rv, Hv = seq_v.shape[1], seq_v.shape[2]
+            cfg = self.config
+
+            def head(x, rows, K, pre, with_ln, decoders):
+                """x bf16 [rows, K] -> transform (dense + GELU (+ LayerNorm)) -> {name: fp32 scores}"""
+                h, gp = torch.empty(rows, K, device=dev, dtype=torch.bfloat16), torch.empty(rows, K, device=dev, dtype=torch.bfloat16)
+                ops.gemm_grouped(L.NT, L.EPI_GELU, [ops.gemm_problem(x, W(pre + "transform.dense.weight"), h, L.NT, rows, K, K, bias=Pm(pre + "transform.dense.bias"), C2=gp)])
+                if with_ln:
+                    hn = torch.empty_like(h)
+                    mean, rstd = torch.empty(rows, device=dev), torch.empty(rows, device=dev)
+                    ops.ln_fwd(h, None, Pm(pre + "transform.LayerNorm.weight"), Pm(pre + "transform.LayerNorm.bias"), hn, None, mean, rstd, rows, K)
+                    h = hn
+                out = {}
+                for name, (wt, bias, C) in decoders.items():
+                    Cp = -(-C // 64) * 64
+                    sc = torch.empty(rows, Cp, device=dev)
+                    ops.gemm_grouped(L.NT, L.EPI_F32, [ops.gemm_problem(h, wt, sc, L.NT, rows, C, K, bias=bias, n_store=Cp)])
+                    out[name] = sc[:, :C]
+                return out
+
+            xt = eng.taps["seq_t"]
+            scores_t = head(xt, B * T, H, "cls.predictions.", True,
+                            {"t": (W("bert.embeddings.word_embeddings.weight"), Pm("cls.predictions.bias"), cfg.vocab_size)})["t"].reshape(B, T, -1)
+            widths = {"0": 1601, "1": 2048, "2": 2048, "3": 1600, "4": 400, "5": 2048, "6": 1601}
+            decs = {ix: (W("cls.imagePredictions.decoder_dict.%s.weight" % ix), Pm("cls.imagePredictions.decoder_dict.%s.bias" % ix), widths[ix])
+                    for ix, w in cfg.visual_target_weights.items() if w > 0}
+            sv = head(eng.taps["seq_v"], B * Rv, Hv, "cls.imagePredictions.", bool(cfg.image_head_ln), decs)
+            scores_v = {ix: t.reshape(B, Rv, -1) for ix, t in sv.items()}
+            fm = self.bert.fusion_method
+            pooled = None if fm == "none" else (pt * pv if fm == "mul" else pt + pv if fm == "sum" else pt)
+            itm = None
+            if fm in ("mul", "sum", "text"):
+                P = pooled.shape[1]
+                pb = pooled.to(torch.bfloat16).contiguous()
+                sc = torch.empty(B, 64, device=dev)
+                ops.gemm_grouped(L.NT, L.EPI_F32, [ops.gemm_problem(pb, W("cls.bi_seq_relationship.weight"), sc, L.NT, B, 2, P, bias=Pm("cls.bi_seq_relationship.bias"), n_store=64)])
+                itm = sc[:, :2]
+            return scores_t, scores_v, itm, ([], []), pooled
 
     def encode(self, input_ids, image_feat, image_loc, token_type_ids=None, attention_mask=None, image_attention_mask=None):
         """BertModel.forward: (seq_t [B,T,H], seq_v [B,Rv,H], pooled_t, pooled_v, attention maps = ([], []))."""
