@@ -83,11 +83,6 @@ int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* probs, int 
 #define VK_GEMM_PERSISTENT 0x1000
 #define VK_GEMM_ONE_TILE_PER_WG 0x2000
 int vk_gemm_grouped_ex(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, int geometry, vk_stream_t s);
-/* Same with a caller-owned workspace (VK_GEMM_WORKSPACE_BYTES, zero-initialised once, used by launches of ONE stream at a time): the
- * persistent tile walk then hands out tiles from a counter in it instead of by a fixed stride, which keeps a launch balanced when part of
- * the CUs is held by kernels of other streams (weight-gradient GEMMs on the side stream, RCCL reductions).  NULL = vk_gemm_grouped_ex. */
-#define VK_GEMM_WORKSPACE_BYTES 64
-int vk_gemm_grouped_ws(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, int geometry, void* workspace, vk_stream_t s);
 
 /* fp8 (OCP e4m3) forward projections on v_mfma_scale_f32_16x16x128_f8f6f4 (BASELINE.json configs[4]; the reference is fp32, the
  * sites are the nn.Linear forwards of volta/encoders.py:242-255, 495-499, 552-565).  Layout NT only: C[M,N] = (A8[M,K] . B8[N,K]^T)
@@ -429,7 +424,7 @@ int vk_mul_bf16(const void* a, const void* b, void* out, int64_t n, const int32_
  * issues them in order on one stream (stops at the first error).  There is no reference counterpart:
  * the reference walks a Python module tree and autograd graph every step (volta/encoders.py:868-881). */
 enum {
-    VK_OP_GEMM = 1,      /* a = vk_gemm_problem[i2], i0 = layout, i1 = epilogue, b = workspace of vk_gemm_grouped_ws or NULL */
+    VK_OP_GEMM = 1,      /* a = vk_gemm_problem[i2], i0 = layout, i1 = epilogue */
     VK_OP_LN_FWD, VK_OP_LN_BWD,   /* a = args, b = args of a second job sharing the launch or NULL */
     VK_OP_ATTN_FWD,
     VK_OP_ATTN_BWD,      /* a = vk_attn_args, b = vk_attn_bwd_args */

@@ -177,41 +177,3 @@ def test_gemm_nn_ragged_contraction_keeps_the_last_row(K):
     assert err <= 1e-2 * max(ref.abs().max().item(), 1.0), (K, err)
     last = (C[-1].float() - ref[-1]).abs().max().item()
     assert last <= 1e-2 * max(ref[-1].abs().max().item(), 1e-3), (K, "last row", last)
-
-
-@pytest.mark.parametrize("layout_name,epi_name", [("NT", "BF16"), ("NN", "MULR"), ("NT", "GELU")])
-def test_gemm_persistent_walk_with_claimed_tiles(layout_name, epi_name):
-    """vk_gemm_grouped_ws: the persistent walk hands out tiles from the caller's counter workspace (balanced when other streams hold CUs).
-    Same results as the reference product, for repeated launches (the last workgroup out resets the counters), counters back at zero."""
-    import ctypes as C
-    L, ops = _mods()
-    layout, epi = getattr(L, layout_name), getattr(L, "EPI_" + epi_name)
-    g = torch.Generator(device="cuda").manual_seed(11)
-    probs, keep, refs = [], [], []
-    for M in (5120, 9472):                      # 684 tiles of 256 x 256 over 256 workgroups, two problems
-        N, K = 3072, 768
-        A = rnd((M, K), g)
-        B = rnd((N, K), g) if layout == L.NT else rnd((K, N), g)
-        Cc = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
-        C2 = torch.empty(M, N, device="cuda", dtype=torch.bfloat16) if epi == L.EPI_GELU else None
-        Rr = rnd((M, N), g) if epi == L.EPI_MULR else None
-        bias = None if epi == L.EPI_MULR else torch.randn(N, generator=g, device="cuda")
-        probs.append(ops.gemm_problem(A, B, Cc, layout, M, N, K, bias=bias, C2=C2, R=Rr))
-        ref = ref_mm(layout, A, B, L) + (bias if bias is not None else 0)
-        if epi == L.EPI_MULR:
-            ref = ref * Rr.float()
-        elif epi == L.EPI_GELU:
-            ref = torch.nn.functional.gelu(ref)
-        keep += [A, B, Cc, C2, Rr, bias]
-        refs.append((Cc, ref))
-    arr = (L.GemmProblem * 2)(*probs)
-    ws = torch.zeros(16, dtype=torch.int32, device="cuda")
-    for it in range(3):
-        for Cc, _ in refs:
-            Cc.fill_(float("nan"))
-        L.check(L.lib.vk_gemm_grouped_ws(layout, epi, arr, 2, 258 | L.GEMM_PERSISTENT, C.c_void_p(ws.data_ptr()), ops.stream_ptr()))
-        torch.cuda.synchronize()
-        assert int(ws.abs().sum()) == 0, ws.tolist()
-        for Cc, ref in refs:
-            err = (Cc.float() - ref).abs().max().item()
-            assert err <= 2e-2 * max(ref.abs().max().item(), 1.0), (it, err)

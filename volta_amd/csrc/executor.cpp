@@ -132,7 +132,7 @@ static int run_one(const vk_op& o, int i, vk_stream_t s) {
     {
         int rc = 0;
         switch (o.kind) {
-            case VK_OP_GEMM: rc = vk_gemm_grouped_ws(o.i0, o.i1, (const vk_gemm_problem*)o.a, o.i2, 0, (void*)o.b, s); break;
+            case VK_OP_GEMM: rc = vk_gemm_grouped(o.i0, o.i1, (const vk_gemm_problem*)o.a, o.i2, s); break;
             case VK_OP_GEMM_FP8: rc = vk_gemm_fp8_grouped(o.i1, (const vk_gemm_fp8_problem*)o.a, o.i2, o.i0, s); break;
             case VK_OP_LN_FWD: rc = vk_ln_fwd_pair((const vk_ln_args*)o.a, (const vk_ln_args*)o.b, s); break;
             case VK_OP_LN_BWD: rc = vk_ln_bwd_pair((const vk_ln_bwd_args*)o.a, (const vk_ln_bwd_args*)o.b, s); break;

@@ -246,7 +246,7 @@ static int total_tiles(const vk_gemm_problem* probs, int nprob, int epilogue, in
 
 }  // namespace vk
 
-static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, int geometry, vk_stream_t stream, int* claim = nullptr) {
+static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, int geometry, vk_stream_t stream) {
     using namespace vk;
     if (nprob < 1 || nprob > VK_GEMM_MAX_GROUP) return set_error("vk_gemm_grouped: nprob %d out of range", nprob);
     const bool f32out = epilogue == VK_EPI_F32 || epilogue == VK_EPI_F32_ACC;
@@ -327,7 +327,7 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
         if (walk == VK_GEMM_PERSISTENT) persistent = persistent && true;
         else if (walk == VK_GEMM_ONE_TILE_PER_WG) persistent = false;
         else persistent = persistent && g_persistent && total > NUM_CU;
-        return launch_gemm256(layout, epilogue, g, total, s, edge == 258 ? 4 : edge == 259 ? 3 : edge == 260 ? 2 : 0, persistent, claim);
+        return launch_gemm256(layout, epilogue, g, total, s, edge == 258 ? 4 : edge == 259 ? 3 : edge == 260 ? 2 : 0, persistent);
     }
     {
         const bool reg = g_regstage_override >= 0 ? g_regstage_override != 0 : layout != VK_NT;
@@ -344,11 +344,6 @@ extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* 
 
 extern "C" int vk_gemm_grouped_ex(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, int geometry, vk_stream_t stream) {
     return gemm_dispatch(layout, epilogue, probs, nprob, geometry, stream);
-}
-
-extern "C" int vk_gemm_grouped_ws(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, int geometry, void* workspace, vk_stream_t stream) {
-    if (workspace && ((uintptr_t)workspace & 7)) return vk::set_error("vk_gemm_grouped_ws: the workspace must be 8-byte aligned");
-    return gemm_dispatch(layout, epilogue, probs, nprob, geometry, stream, (int*)workspace);
 }
 
 #ifdef VK_STUDY

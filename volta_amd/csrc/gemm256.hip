@@ -371,13 +371,8 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
 // retires, and launch ramp + end-of-kernel write-back are paid once per launch instead of once per round.
 // vmcnt counts loads and stores together in issue order: the next tile's prologue loads are OLDER than the epilogue's stores, so the
 // loop's first `vmcnt(8)` (all but the 8 youngest operations done) covers them -- conservatively, it also waits for most stores.
-// Tile hand-out: with `claim` (two zero-initialised ints the caller owns; NULL = static striding) every workgroup takes its FIRST tile by its
-// index and every further one from a global counter, so a workgroup that starts late -- its CU was held by a kernel of another stream: a
-// weight-gradient GEMM on the side stream, an RCCL reduction of the data-parallel wrapper -- finds the list already shortened instead of
-// running its fixed share after everyone else has finished (a 256 x 256 workgroup needs a whole CU: with 32 of 256 CUs held elsewhere the
-// static walk lasts twice as long, the claimed one 14 % longer).  The last workgroup to leave resets both counters for the next launch.
 template <bool AT, bool BT, int EPI, int TJ>
-__global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int total, unsigned long long* const stamps, int* const claim) {
+__global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int total, unsigned long long* const stamps) {
     // `stamps` (study builds; NULL in the shipped library's launches): per workgroup and tile four s_memrealtime readings (100 MHz) --
     // loop top, K loop done, ring drained + next prologue issued, epilogue done -- into a buffer no other code reads.
     static_assert(!(AT && BT), "the persistent kernel serves the NT / NN layouts (no bias-gradient accumulators)");
@@ -461,19 +456,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int
         }
         if (wr == 0) VK_SYNC();
         if (stamping) st[1] = __builtin_amdgcn_s_memrealtime();
-        int claimed = 0;
-        if (claim && tid == 0) claimed = atomicAdd(claim, 1);   // in flight while the ring drains
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // retire the zero-fill stages issued past the end of K
         VK_SYNC();                                            // ... of every wave: the whole ring is free
 
         const int cpi = pi, cm0 = m0, cn0 = n0;
-        int nv = v + (int)gridDim.x;
-        if (claim) {                                          // publish the claimed index through the (free) first word of the ring
-            if (tid == 0) *(volatile int VK_LDS*)(uintptr_t)lds0 = (int)gridDim.x + claimed;
-            __syncthreads();
-            nv = __builtin_amdgcn_readfirstlane(*(volatile int VK_LDS*)(uintptr_t)lds0);
-            __syncthreads();                                  // every wave has it before anyone's prologue overwrites the slot
-        }
+        const int nv = v + (int)gridDim.x;
         const bool more = nv < total;
         if (more) {                                           // next tile's operands first, then this tile's output
             setup(nv);
@@ -487,10 +474,6 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int
         if (!more) break;
         v = nv;
     }
-    if (claim && tid == 0 && atomicAdd(claim + 1, 1) == (int)gridDim.x - 1) {      // the last one out: everybody has stopped claiming
-        claim[0] = 0;
-        claim[1] = 0;
-    }
 }
 
 #ifdef VK_STUDY
@@ -500,7 +483,7 @@ static constexpr unsigned long long* g_stamps = nullptr;
 #endif
 
 template <bool AT, bool BT, int KSPLIT>      // 4 / 3 / 2: K-split kernel with 256 / 192 / 128 columns; 0: 4-phase 256 x 256 (study builds)
-static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s, bool persistent, int* claim) {
+static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s, bool persistent) {
     constexpr int LDS = (KSPLIT ? 10 : 8) * HT;
 #ifdef VK_STUDY
 #define VK_KERNEL_OF(E) (KSPLIT == 2 ? gemm256k_kernel<AT, BT, E, 2> : KSPLIT == 3 ? gemm256k_kernel<AT, BT, E, 3> : KSPLIT == 4 ? gemm256k_kernel<AT, BT, E, 4> : gemm256_kernel<AT, BT, E>)
@@ -513,7 +496,7 @@ static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s, boo
             if (persistent) {                                                                             \
                 auto kp = gemm256p_kernel<AT, BT, E, KSPLIT>;                                             \
                 static const hipError_t attr_p = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); (void)attr_p; \
-                hipLaunchKernelGGL(kp, dim3(total < NUM_CU ? total : NUM_CU), dim3(512), LDS, s, g, total, g_stamps, claim); \
+                hipLaunchKernelGGL(kp, dim3(total < NUM_CU ? total : NUM_CU), dim3(512), LDS, s, g, total, g_stamps); \
                 break;                                                                                    \
             }                                                                                             \
         }                                                                                                 \
@@ -532,19 +515,19 @@ static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s, boo
 }
 
 template <int KSPLIT>
-static int launch_variant(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, bool persistent, int* claim) {
-    if (layout == VK_NT) return launch_layout<false, false, KSPLIT>(epilogue, g, total, s, persistent, claim);
-    if (layout == VK_NN) return launch_layout<false, true, KSPLIT>(epilogue, g, total, s, persistent, claim);
-    if (layout == VK_TN) return launch_layout<true, true, KSPLIT>(epilogue, g, total, s, false, nullptr);
+static int launch_variant(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, bool persistent) {
+    if (layout == VK_NT) return launch_layout<false, false, KSPLIT>(epilogue, g, total, s, persistent);
+    if (layout == VK_NN) return launch_layout<false, true, KSPLIT>(epilogue, g, total, s, persistent);
+    if (layout == VK_TN) return launch_layout<true, true, KSPLIT>(epilogue, g, total, s, false);
     return set_error("vk_gemm_grouped: unknown layout %d", layout);
 }
 
-int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant, bool persistent, int* claim) {
-    if (variant == 2) return launch_variant<2>(layout, epilogue, g, total, s, false, nullptr);
-    if (variant == 3) return launch_variant<3>(layout, epilogue, g, total, s, persistent, claim);
-    if (variant == 4) return launch_variant<4>(layout, epilogue, g, total, s, persistent, claim);
+int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant, bool persistent) {
+    if (variant == 2) return launch_variant<2>(layout, epilogue, g, total, s, false);
+    if (variant == 3) return launch_variant<3>(layout, epilogue, g, total, s, persistent);
+    if (variant == 4) return launch_variant<4>(layout, epilogue, g, total, s, persistent);
 #ifdef VK_STUDY
-    return launch_variant<0>(layout, epilogue, g, total, s, false, nullptr);
+    return launch_variant<0>(layout, epilogue, g, total, s, false);
 #else
     return set_error("vk_gemm_grouped: geometry variant %d is not part of this build", variant);
 #endif

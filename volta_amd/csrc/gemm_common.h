@@ -303,6 +303,6 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
 // 256-row tiles, 8 waves, LDS-DMA ring (gemm256.hip).  variant 4 / 3 / 2: K-split kernel with 256 / 192 / 128 columns; 0: the 4-phase
 // study kernel (VK_STUDY builds only).  persistent: one workgroup per CU walks the tile list (NT / NN, no device-side row counts).
 constexpr int NUM_CU = 256;       // MI355X
-int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant, bool persistent, int* claim);
+int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant, bool persistent);
 
 }  // namespace vk

@@ -485,19 +485,6 @@ class StepEngine:
         self.param_ready_stage = {}
         for name in self.arena.params:
             self.param_ready_stage[name] = max(i for i, pf in enumerate(prefixes) if any(name.startswith(q) for q in pf))
-        # GEMM launches on the caller's stream get the claim counters of vk_gemm_grouped_ws (the persistent tile walk then stays balanced when
-        # kernels of other streams -- side-stream weight gradients, RCCL reductions -- hold part of the CUs); side-stream launches do not
-        # (the workspace serves one stream at a time)
-        ws = self.buf("gemm_claim", (16,), torch.int32, zero=True)
-        for plan in (self.fwd, self.bwd):
-            side = False
-            for i, op in enumerate(plan.ops):
-                if op[0] == L.OP_SIDE_BEGIN:
-                    side = True
-                elif op[0] == L.OP_SIDE_END:
-                    side = False
-                elif op[0] == L.OP_GEMM and not side:
-                    plan.ops[i] = op[:5] + (ws,) + op[6:]
         self.fwd.freeze()
         self.bwd.freeze()
 
