@@ -42,12 +42,27 @@ __global__ __launch_bounds__(256) void embed_sum_fwd_kernel(vk_embed_args a) {
     }
 }
 
-// word table: atomics (rows collide only on repeated ids); type table (<= 4 rows, every row of the batch
-// hits them): per-workgroup partial sums first, one atomic per workgroup and column afterwards.
+// Word table: float atomics, but only ONE per workgroup, column and distinct id.  A workgroup takes 32 rows of the SAME position t (samples
+// b0 .. b0+31: row = b * T + t), because that is where ids repeat -- [CLS] at t = 0 and [SEP] at the caption's end in every sample, [MASK] on
+// 15 % of the rest -- and the first row of every id inside the workgroup sums its duplicates before it touches the table.  (One atomic per
+// row and column made 256-700 of them queue on the same address for the three hot ids: 110 us for 5120 x 768, on the critical path of the step.)
+// Type table (<= 4 rows, every row of the batch hits them): per-workgroup partial sums first, one atomic per workgroup and column afterwards.
 template <int NCH>
 __global__ __launch_bounds__(256) void embed_scatter_kernel(vk_embed_bwd_args a) {
     __shared__ float red[4][4][NCH * 256];
+    __shared__ int64_t id_s[32];
+    __shared__ int ty_s[32], row_s[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nb = a.M / a.T;                                  // samples
+    if (threadIdx.x < 32) {
+        const int i = blockIdx.x * 32 + (int)threadIdx.x;      // position-major index: i = t * nb + b
+        int row = -1;
+        if (i < a.M) { const int t = i / nb, b = i - t * nb; row = b * a.T + t; }
+        row_s[threadIdx.x] = row;
+        id_s[threadIdx.x] = row >= 0 ? clampi(a.ids[row], a.V) : -1;
+        ty_s[threadIdx.x] = (row >= 0 && a.type_ids) ? (int)clampi(a.type_ids[row], a.n_types) : 0;
+    }
+    __syncthreads();
     float ta[4][NCH][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -56,24 +71,70 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(vk_embed_bwd_args a)
 #pragma unroll
             for (int r = 0; r < 4; ++r) ta[k][j][r] = 0.f;
     for (int it = 0; it < 8; ++it) {
-        const int row = blockIdx.x * 32 + it * 4 + wave;
-        if (row >= a.M) break;
-        const int64_t id = clampi(a.ids[row], a.V);
-        const int ty = a.type_ids ? (int)clampi(a.type_ids[row], a.n_types) : 0;
+        const int r0 = it * 4 + wave;
+        const int row = row_s[r0];
+        if (row < 0) continue;
+        const int64_t id = id_s[r0];
+        bool first = true;                                     // wave-uniform: is this the workgroup's first row with this id?
+        for (int q = 0; q < r0; ++q) first &= id_s[q] != id;
         const int64_t ps = a.pos_ids ? clampi(a.pos_ids[row], a.P) : -1;
+        if (ps >= 0) {                                         // explicit positions (VL-BERT): per row, as before
+#pragma unroll
+            for (int j = 0; j < NCH; ++j) {
+                const int c = j * 256 + lane * 4;
+                if (c < a.H) {
+                    float v[4];
+                    ld4((const uint16_t*)a.dz + (size_t)row * a.H + c, v);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) atomicAdd(a.dpos + (size_t)ps * a.H + c + r, v[r]);
+                }
+            }
+        }
+        if (!first) continue;
+        float acc[NCH][4];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[j][r] = 0.f;
+        // this row and its duplicates further down, four rows' loads in flight at a time ([CLS] at t = 0: all 32 rows of the workgroup)
+        unsigned long long dup = __ballot(lane < 32 && lane >= r0 && id_s[lane & 31] == id && row_s[lane & 31] >= 0);
+        while (dup) {
+            int qs[4], n = 0;
+            for (; n < 4 && dup; ++n) { qs[n] = __builtin_ctzll(dup); dup &= dup - 1; }
+            float v[4][NCH][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < n) {
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) {
+                        const int c = j * 256 + lane * 4;
+                        if (c < a.H) ld4((const uint16_t*)a.dz + (size_t)row_s[qs[u]] * a.H + c, v[u][j]);
+                    }
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (u < n) {
+                    const int ty = ty_s[qs[u]];
+#pragma unroll
+                    for (int j = 0; j < NCH; ++j) {
+                        const int c = j * 256 + lane * 4;
+                        if (c < a.H) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                acc[j][r] += v[u][j][r];
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) ta[k][j][r] += (ty == k) ? v[u][j][r] : 0.f;
+                            }
+                        }
+                    }
+                }
+        }
 #pragma unroll
         for (int j = 0; j < NCH; ++j) {
             const int c = j * 256 + lane * 4;
             if (c < a.H) {
-                float v[4];
-                ld4((const uint16_t*)a.dz + (size_t)row * a.H + c, v);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    atomicAdd(a.dword + (size_t)id * a.H + c + r, v[r]);
-                    if (ps >= 0) atomicAdd(a.dpos + (size_t)ps * a.H + c + r, v[r]);
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) ta[k][j][r] += (ty == k) ? v[r] : 0.f;
-                }
+                for (int r = 0; r < 4; ++r) atomicAdd(a.dword + (size_t)id * a.H + c + r, acc[j][r]);
             }
         }
     }
@@ -453,6 +514,7 @@ extern "C" int vk_embed_sum_bwd(const vk_embed_bwd_args* a, vk_stream_t s) {
     if (a->H % 4 || a->H > 1024) return set_error("vk_embed_sum_bwd: H must be a multiple of 4, <= 1024");
     if (a->n_types > 4) return set_error("vk_embed_sum_bwd: at most 4 token types");
     if (a->M <= 0) return 0;
+    if (a->T <= 0 || a->M % a->T) return set_error("vk_embed_sum_bwd: M must be a multiple of T (rows are b * T + t)");
     const int nch = (a->H + 255) / 256;
     dim3 grid((a->M + 31) / 32), block(256);
     hipStream_t st = (hipStream_t)s;
