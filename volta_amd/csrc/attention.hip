@@ -8,31 +8,36 @@
 // one wave's task.  MFMAs are issued in the swapped orientation (D = K Q^T) so that a lane owns one
 // query and the accumulator tile is directly the next MFMA's B operand (no LDS round trip for P).
 // Scores never touch HBM; the backward recomputes P from the saved log-sum-exp.
-// dh is fixed at 64 (every ctrl_* config); sequence lengths up to 64 text / 128 vision tokens.
+// Head size 64 (every ctrl_* config) or 128 (config/vilbert_base.json), a template parameter; sequence lengths up to 64 text / 128 vision
+// tokens (128-wide heads: up to 96 padded rows, beyond that and for other head sizes attention_generic.hip).
 #include "common.h"
 #include "../../include/volta_hip.h"
 #include "util.h"
 
 namespace vk {
 
-constexpr int DH = 64;
 
-// dual-use LDS image of a [rows][64] bf16 tile: 128-B rows, 32-B blocks XOR-swizzled by (row>>1)&3
+
+// dual-use LDS image of a [rows][DHT] bf16 tile: rows of 2 DHT bytes (128 for the 64-wide heads of every ctrl_* config, 256 for the 128-wide
+// heads of config/vilbert_base.json), 32-B blocks XOR-swizzled by (row>>1)&3
+template <int DHT>
 __device__ __forceinline__ uint32_t img_off(int row, int col) {
-    return (uint32_t)(row * 128 + ((((col >> 4) ^ ((row >> 1) & 3)) << 5) | ((col & 15) << 1)));
+    return (uint32_t)(row * (2 * DHT) + ((((col >> 4) ^ ((row >> 1) & 3)) << 5) | ((col & 15) << 1)));
 }
 // 8 consecutive dims [c8, c8+8) of one row: MFMA fragment for rows = (lane&15), k = dims
+template <int DHT>
 __device__ __forceinline__ bf16x8 img_row_frag(uint32_t img, int row0, int ks, int lane) {
     const int row = row0 + (lane & 15);
-    return *(const bf16x8 VK_LDS*)(uintptr_t)(img + img_off(row, ks * 32 + (lane >> 4) * 8));
+    return *(const bf16x8 VK_LDS*)(uintptr_t)(img + img_off<DHT>(row, ks * 32 + (lane >> 4) * 8));
 }
 // transposed fragment: output rows = the 16 dims [d0, d0+16), k = 32 tile rows in "pair order":
 // slot j<4 of lane group g is row rbase + 4g + j, slot j>=4 is row rbase + 16 + 4g + (j-4).
+template <int DHT>
 __device__ __forceinline__ bf16x8 img_tr_frag(uint32_t img, int rbase, int d0, int lane) {
     const int g = lane >> 4, q = (lane & 15) >> 2, p = lane & 3;
     const int r0 = rbase + 4 * g + q, r1 = r0 + 16;
-    bf16x4 lo = lds_read_tr16(img + img_off(r0, d0 + 4 * p));
-    bf16x4 hi = lds_read_tr16(img + img_off(r1, d0 + 4 * p));
+    bf16x4 lo = lds_read_tr16(img + img_off<DHT>(r0, d0 + 4 * p));
+    bf16x4 hi = lds_read_tr16(img + img_off<DHT>(r1, d0 + 4 * p));
     bf16x8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
@@ -44,31 +49,34 @@ __device__ __forceinline__ bf16x8 img_tr_frag(uint32_t img, int rbase, int d0, i
 // modalities) and only then writes LDS, so the workgroup pays one memory latency instead of one per image
 // (staging image after image cost 8-12 dependent round trips, most of a backward workgroup's lifetime).
 // Needs >= 256 threads (pieces per thread are sized for 256).
-template <int RPAD> struct StagePieces { static constexpr int N = (RPAD * 8 + 255) / 256; };
-template <int RPAD>
-__device__ __forceinline__ void stage_load(u32x4 (&r)[StagePieces<RPAD>::N], const uint16_t* base, int ld, int L, int tid, int nthr) {
+template <int RPAD, int DHT> struct StagePieces { static constexpr int CH = DHT / 8, N = (RPAD * CH + 255) / 256; };      // CH 16-byte pieces per row
+template <int RPAD, int DHT>
+__device__ __forceinline__ void stage_load(u32x4 (&r)[(StagePieces<RPAD, DHT>::N)], const uint16_t* base, int ld, int L, int tid, int nthr) {
+    constexpr int CH = DHT / 8;
 #pragma unroll
-    for (int i = 0; i < StagePieces<RPAD>::N; ++i) {
-        const int idx = i * nthr + tid, row = idx >> 3, ch = idx & 7;
+    for (int i = 0; i < StagePieces<RPAD, DHT>::N; ++i) {
+        const int idx = i * nthr + tid, row = idx / CH, ch = idx % CH;
         r[i] = u32x4{0u, 0u, 0u, 0u};
-        if (idx < RPAD * 8 && row < L) r[i] = *(const u32x4*)(base + (size_t)row * ld + ch * 8);
+        if (idx < RPAD * CH && row < L) r[i] = *(const u32x4*)(base + (size_t)row * ld + ch * 8);
     }
 }
-template <int RPAD>
-__device__ __forceinline__ void stage_store(uint32_t img, const u32x4 (&r)[StagePieces<RPAD>::N], int tid, int nthr) {
+template <int RPAD, int DHT>
+__device__ __forceinline__ void stage_store(uint32_t img, const u32x4 (&r)[(StagePieces<RPAD, DHT>::N)], int tid, int nthr) {
+    constexpr int CH = DHT / 8;
 #pragma unroll
-    for (int i = 0; i < StagePieces<RPAD>::N; ++i) {
-        const int idx = i * nthr + tid, row = idx >> 3, ch = idx & 7;
-        if (idx < RPAD * 8) *(u32x4 VK_LDS*)(uintptr_t)(img + img_off(row, ch * 8)) = r[i];
+    for (int i = 0; i < StagePieces<RPAD, DHT>::N; ++i) {
+        const int idx = i * nthr + tid, row = idx / CH, ch = idx % CH;
+        if (idx < RPAD * CH) *(u32x4 VK_LDS*)(uintptr_t)(img + img_off<DHT>(row, ch * 8)) = r[i];
     }
 }
-// delta[row] = sum_d dO[row][d] * O[row][d] from the staged registers (8 lanes per row), plus the lse copy
-template <int RPAD>
-__device__ __forceinline__ void delta_rows(const u32x4 (&rg)[StagePieces<RPAD>::N], const u32x4 (&ro)[StagePieces<RPAD>::N], float VK_LDS* del_s,
+// delta[row] = sum_d dO[row][d] * O[row][d] from the staged registers (DHT / 8 lanes per row), plus the lse copy
+template <int RPAD, int DHT>
+__device__ __forceinline__ void delta_rows(const u32x4 (&rg)[(StagePieces<RPAD, DHT>::N)], const u32x4 (&ro)[(StagePieces<RPAD, DHT>::N)], float VK_LDS* del_s,
                                            float VK_LDS* lse_s, const float* lse, int L, int tid, int nthr) {
+    constexpr int CH = DHT / 8;
 #pragma unroll
-    for (int i = 0; i < StagePieces<RPAD>::N; ++i) {
-        const int idx = i * nthr + tid, row = idx >> 3, ch = idx & 7;
+    for (int i = 0; i < StagePieces<RPAD, DHT>::N; ++i) {
+        const int idx = i * nthr + tid, row = idx / CH, ch = idx % CH;
         float part = 0.f;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
@@ -76,7 +84,8 @@ __device__ __forceinline__ void delta_rows(const u32x4 (&rg)[StagePieces<RPAD>::
         part += __shfl_xor(part, 1, 64);
         part += __shfl_xor(part, 2, 64);
         part += __shfl_xor(part, 4, 64);
-        if (ch == 0 && idx < RPAD * 8) {
+        if (CH > 8) part += __shfl_xor(part, 8, 64);
+        if (ch == 0 && idx < RPAD * CH) {
             del_s[row] = part;
             lse_s[row] = row < L ? lse[row] : 0.f;
         }
@@ -126,13 +135,14 @@ struct AttnK {                       // kernel-side copy of vk_attn_args (+ back
 template <int P0, int P1> struct Pads { static constexpr int P[2] = {P0, P1}; };
 
 // ------------------------------------------------------------------------------------------------ forward
-template <int TP, int RP, int OCC>
+template <int TP, int RP, int OCC, int DHT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void attn_fwd_kernel(const AttnK a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(VK_LDS char*)smem;
     constexpr int NKT[2] = {TP / 16, RP / 16};
-    const uint32_t kimg[2] = {lds0, lds0 + TP * 128};
-    const uint32_t vimg[2] = {lds0 + (TP + RP) * 128, lds0 + (TP + RP) * 128 + TP * 128};
+    constexpr int RB = 2 * DHT, KS = DHT / 32, DT = DHT / 16;      // image row bytes, 32-deep contraction steps, 16-wide output tiles per head
+    const uint32_t kimg[2] = {lds0, lds0 + TP * RB};
+    const uint32_t vimg[2] = {lds0 + (TP + RP) * RB, lds0 + (TP + RP) * RB + TP * RB};
     const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
     const int b = blockIdx.x / a.nh, h = blockIdx.x - b * a.nh;
     const int g = lane >> 4, lq = lane & 15;
@@ -140,18 +150,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     {
         const int nthr = blockDim.x;
         const bool k0 = a.gate[0][0] || a.gate[1][0], k1 = a.gate[0][1] || a.gate[1][1];
-        u32x4 rk0[StagePieces<TP>::N], rv0[StagePieces<TP>::N], rk1[StagePieces<RP>::N], rv1[StagePieces<RP>::N];
+        u32x4 rk0[StagePieces<TP, DHT>::N], rv0[StagePieces<TP, DHT>::N], rk1[StagePieces<RP, DHT>::N], rv1[StagePieces<RP, DHT>::N];
         if (k0) {
-            stage_load<TP>(rk0, a.k[0] + ((size_t)b * a.L[0]) * a.ld[0] + h * DH, a.ld[0], a.L[0], tid, nthr);
-            stage_load<TP>(rv0, a.v[0] + ((size_t)b * a.L[0]) * a.ld[0] + h * DH, a.ld[0], a.L[0], tid, nthr);
+            stage_load<TP, DHT>(rk0, a.k[0] + ((size_t)b * a.L[0]) * a.ld[0] + h * DHT, a.ld[0], a.L[0], tid, nthr);
+            stage_load<TP, DHT>(rv0, a.v[0] + ((size_t)b * a.L[0]) * a.ld[0] + h * DHT, a.ld[0], a.L[0], tid, nthr);
         }
         if (k1) {
-            stage_load<RP>(rk1, a.k[1] + ((size_t)b * a.L[1]) * a.ld[1] + h * DH, a.ld[1], a.L[1], tid, nthr);
-            stage_load<RP>(rv1, a.v[1] + ((size_t)b * a.L[1]) * a.ld[1] + h * DH, a.ld[1], a.L[1], tid, nthr);
+            stage_load<RP, DHT>(rk1, a.k[1] + ((size_t)b * a.L[1]) * a.ld[1] + h * DHT, a.ld[1], a.L[1], tid, nthr);
+            stage_load<RP, DHT>(rv1, a.v[1] + ((size_t)b * a.L[1]) * a.ld[1] + h * DHT, a.ld[1], a.L[1], tid, nthr);
         }
-        if (k0) { stage_store<TP>(kimg[0], rk0, tid, nthr); stage_store<TP>(vimg[0], rv0, tid, nthr); }
-        if (k1) { stage_store<RP>(kimg[1], rk1, tid, nthr); stage_store<RP>(vimg[1], rv1, tid, nthr); }
-        if (tid == 0) *(int VK_LDS*)(uintptr_t)(lds0 + 2 * (TP + RP) * 128) = 0;
+        if (k0) { stage_store<TP, DHT>(kimg[0], rk0, tid, nthr); stage_store<TP, DHT>(vimg[0], rv0, tid, nthr); }
+        if (k1) { stage_store<RP, DHT>(kimg[1], rk1, tid, nthr); stage_store<RP, DHT>(vimg[1], rv1, tid, nthr); }
+        if (tid == 0) *(int VK_LDS*)(uintptr_t)(lds0 + 2 * (TP + RP) * RB) = 0;
     }
     __syncthreads();
 
@@ -159,7 +169,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     const int nqt1 = (a.gate[1][0] || a.gate[1][1]) ? (a.L[1] + 15) / 16 : 0;
     // Tasks (16-query tiles) are claimed from a counter in LDS, vision tiles (more keys per tile) first: 5 tiles on 4 waves in fixed
     // round-robin order left one wave with text + vision tile while the others idled.
-    int VK_LDS* const next_task = (int VK_LDS*)(uintptr_t)(lds0 + 2 * (TP + RP) * 128);
+    int VK_LDS* const next_task = (int VK_LDS*)(uintptr_t)(lds0 + 2 * (TP + RP) * RB);
     (void)nwaves;
     for (;;) {
         int task = 0;
@@ -172,9 +182,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         const int qi = qt * 16 + lq;
         const bool qvalid = qi < Lq;
         const int qc = qvalid ? qi : Lq - 1;
-        const uint16_t* qrow = a.q[mq] + ((size_t)b * Lq + qc) * a.ld[mq] + h * DH;
-        const bf16x8 qf0 = *(const bf16x8*)(qrow + g * 8);
-        const bf16x8 qf1 = *(const bf16x8*)(qrow + 32 + g * 8);
+        const uint16_t* qrow = a.q[mq] + ((size_t)b * Lq + qc) * a.ld[mq] + h * DHT;
+        bf16x8 qf[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qrow + ks * 32 + g * 8);
 
         f32x4 s0[NKT[0]], s1[NKT[1]];
         float mx = -INFINITY;
@@ -184,8 +195,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             S[kt] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};                                     \
             if (a.gate[mq][MK] && kt * 16 < a.L[MK]) {                                                     \
                 f32x4 acc = {0.f, 0.f, 0.f, 0.f};                                                          \
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg[MK], kt * 16, 0, lane), qf0, acc, 0, 0, 0); \
-                acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg[MK], kt * 16, 1, lane), qf1, acc, 0, 0, 0); \
+                _Pragma("unroll") for (int ks = 0; ks < KS; ++ks)                                          \
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag<DHT>(kimg[MK], kt * 16, ks, lane), qf[ks], acc, 0, 0, 0); \
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
                     const int key = kt * 16 + 4 * g + r;                                                   \
                     if (key < a.L[MK]) {                                                                   \
@@ -213,9 +224,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         if (qvalid && g == 0) a.lse[mq][((size_t)b * a.nh + h) * Lq + qi] = mx + __logf(sum);
         const uint32_t drow = (uint32_t)(((size_t)b * a.nh + h) * Lq + qc);
 
-        f32x4 o[4];
+        f32x4 o[DT];
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int dt = 0; dt < DT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define VK_PV(MK, S)                                                                                       \
         if (a.gate[mq][MK]) {                                                                              \
             const vk_dropout dc = a.drop[mq][MK];                                                          \
@@ -231,8 +242,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             _Pragma("unroll") for (int pp = 0; pp < NKT[MK] / 2; ++pp) {                                   \
                 if (pp * 32 < a.L[MK]) {                                                                   \
                     const bf16x8 pb = pack_pair(S[2 * pp], S[2 * pp + 1]);                                 \
-                    _Pragma("unroll") for (int dt = 0; dt < 4; ++dt)                                       \
-                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(vimg[MK], pp * 32, dt * 16, lane), pb, o[dt], 0, 0, 0); \
+                    _Pragma("unroll") for (int dt = 0; dt < DT; ++dt)                                      \
+                        o[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag<DHT>(vimg[MK], pp * 32, dt * 16, lane), pb, o[dt], 0, 0, 0); \
                 }                                                                                          \
             }                                                                                              \
         }
@@ -240,9 +251,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         VK_PV(1, s1)
 #undef VK_PV
         if (qvalid) {
-            uint16_t* orow = a.ctx[mq] + ((size_t)b * Lq + qi) * a.ldo[mq] + h * DH + 4 * g;
+            uint16_t* orow = a.ctx[mq] + ((size_t)b * Lq + qi) * a.ldo[mq] + h * DHT + 4 * g;
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt)
+            for (int dt = 0; dt < DT; ++dt)
                 *(u32x2*)(orow + dt * 16) = u32x2{pack2bf(o[dt][0], o[dt][1]), pack2bf(o[dt][2], o[dt][3])};
         }
     }
@@ -251,7 +262,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
 // ------------------------------------------------------------------------------------------------ backward
 // OCC = waves per SIMD the register allocation is tuned for: 2 -> <= 256 VGPRs (one 8-wave workgroup per CU), 3 -> <= 168
 // VGPRs so that two 5-wave workgroups share a CU and one's staging phase overlaps the other's MFMA phase.
-template <int TP, int RP, int OCC>
+template <int TP, int RP, int OCC, int DHT>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC))) void attn_bwd_kernel(const AttnK a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(VK_LDS char*)smem;
@@ -259,11 +270,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     constexpr int NKT[2] = {TP / 16, RP / 16};
     constexpr int ROWS = TP + RP;
     // images: Q, K, V, dO for both modalities; then lse[ROWS], delta[ROWS] floats
-    const uint32_t qimg[2] = {lds0, lds0 + TP * 128};
-    const uint32_t kimg[2] = {qimg[0] + ROWS * 128, qimg[1] + ROWS * 128};
-    const uint32_t vimg[2] = {kimg[0] + ROWS * 128, kimg[1] + ROWS * 128};
-    const uint32_t gimg[2] = {vimg[0] + ROWS * 128, vimg[1] + ROWS * 128};
-    float VK_LDS* lse_s = (float VK_LDS*)(uintptr_t)(lds0 + 4 * ROWS * 128);
+    constexpr int RB = 2 * DHT, KS = DHT / 32, DT = DHT / 16;      // image row bytes, 32-deep contraction steps, 16-wide output tiles per head
+    const uint32_t qimg[2] = {lds0, lds0 + TP * RB};
+    const uint32_t kimg[2] = {qimg[0] + ROWS * RB, qimg[1] + ROWS * RB};
+    const uint32_t vimg[2] = {kimg[0] + ROWS * RB, kimg[1] + ROWS * RB};
+    const uint32_t gimg[2] = {vimg[0] + ROWS * RB, vimg[1] + ROWS * RB};
+    float VK_LDS* lse_s = (float VK_LDS*)(uintptr_t)(lds0 + 4 * ROWS * RB);
     float VK_LDS* del_s = lse_s + ROWS;
     const int rbase[2] = {0, TP};
     const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
@@ -279,37 +291,37 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     {
         const int nthr = blockDim.x;
         const size_t r0 = (size_t)b * a.L[0], r1 = (size_t)b * a.L[1];
-        u32x4 rk0[StagePieces<TP>::N], rv0[StagePieces<TP>::N], rq0[StagePieces<TP>::N], rg0[StagePieces<TP>::N], ro0[StagePieces<TP>::N];
-        u32x4 rk1[StagePieces<RP>::N], rv1[StagePieces<RP>::N], rq1[StagePieces<RP>::N], rg1[StagePieces<RP>::N], ro1[StagePieces<RP>::N];
+        u32x4 rk0[StagePieces<TP, DHT>::N], rv0[StagePieces<TP, DHT>::N], rq0[StagePieces<TP, DHT>::N], rg0[StagePieces<TP, DHT>::N], ro0[StagePieces<TP, DHT>::N];
+        u32x4 rk1[StagePieces<RP, DHT>::N], rv1[StagePieces<RP, DHT>::N], rq1[StagePieces<RP, DHT>::N], rg1[StagePieces<RP, DHT>::N], ro1[StagePieces<RP, DHT>::N];
         if (kact[0]) {
-            stage_load<TP>(rk0, a.k[0] + r0 * a.ld[0] + h * DH, a.ld[0], a.L[0], tid, nthr);
-            stage_load<TP>(rv0, a.v[0] + r0 * a.ld[0] + h * DH, a.ld[0], a.L[0], tid, nthr);
+            stage_load<TP, DHT>(rk0, a.k[0] + r0 * a.ld[0] + h * DHT, a.ld[0], a.L[0], tid, nthr);
+            stage_load<TP, DHT>(rv0, a.v[0] + r0 * a.ld[0] + h * DHT, a.ld[0], a.L[0], tid, nthr);
         }
         if (qact[0]) {
-            stage_load<TP>(rq0, a.q[0] + r0 * a.ld[0] + h * DH, a.ld[0], a.L[0], tid, nthr);
-            stage_load<TP>(rg0, a.dctx[0] + r0 * a.ldo[0] + h * DH, a.ldo[0], a.L[0], tid, nthr);
-            stage_load<TP>(ro0, a.ctx[0] + r0 * a.ldo[0] + h * DH, a.ldo[0], a.L[0], tid, nthr);
+            stage_load<TP, DHT>(rq0, a.q[0] + r0 * a.ld[0] + h * DHT, a.ld[0], a.L[0], tid, nthr);
+            stage_load<TP, DHT>(rg0, a.dctx[0] + r0 * a.ldo[0] + h * DHT, a.ldo[0], a.L[0], tid, nthr);
+            stage_load<TP, DHT>(ro0, a.ctx[0] + r0 * a.ldo[0] + h * DHT, a.ldo[0], a.L[0], tid, nthr);
         }
         if (kact[1]) {
-            stage_load<RP>(rk1, a.k[1] + r1 * a.ld[1] + h * DH, a.ld[1], a.L[1], tid, nthr);
-            stage_load<RP>(rv1, a.v[1] + r1 * a.ld[1] + h * DH, a.ld[1], a.L[1], tid, nthr);
+            stage_load<RP, DHT>(rk1, a.k[1] + r1 * a.ld[1] + h * DHT, a.ld[1], a.L[1], tid, nthr);
+            stage_load<RP, DHT>(rv1, a.v[1] + r1 * a.ld[1] + h * DHT, a.ld[1], a.L[1], tid, nthr);
         }
         if (qact[1]) {
-            stage_load<RP>(rq1, a.q[1] + r1 * a.ld[1] + h * DH, a.ld[1], a.L[1], tid, nthr);
-            stage_load<RP>(rg1, a.dctx[1] + r1 * a.ldo[1] + h * DH, a.ldo[1], a.L[1], tid, nthr);
-            stage_load<RP>(ro1, a.ctx[1] + r1 * a.ldo[1] + h * DH, a.ldo[1], a.L[1], tid, nthr);
+            stage_load<RP, DHT>(rq1, a.q[1] + r1 * a.ld[1] + h * DHT, a.ld[1], a.L[1], tid, nthr);
+            stage_load<RP, DHT>(rg1, a.dctx[1] + r1 * a.ldo[1] + h * DHT, a.ldo[1], a.L[1], tid, nthr);
+            stage_load<RP, DHT>(ro1, a.ctx[1] + r1 * a.ldo[1] + h * DHT, a.ldo[1], a.L[1], tid, nthr);
         }
-        if (kact[0]) { stage_store<TP>(kimg[0], rk0, tid, nthr); stage_store<TP>(vimg[0], rv0, tid, nthr); }
+        if (kact[0]) { stage_store<TP, DHT>(kimg[0], rk0, tid, nthr); stage_store<TP, DHT>(vimg[0], rv0, tid, nthr); }
         if (qact[0]) {
-            stage_store<TP>(qimg[0], rq0, tid, nthr); stage_store<TP>(gimg[0], rg0, tid, nthr);
-            delta_rows<TP>(rg0, ro0, del_s + rbase[0], lse_s + rbase[0], a.lse[0] + ((size_t)b * a.nh + h) * a.L[0], a.L[0], tid, nthr);
+            stage_store<TP, DHT>(qimg[0], rq0, tid, nthr); stage_store<TP, DHT>(gimg[0], rg0, tid, nthr);
+            delta_rows<TP, DHT>(rg0, ro0, del_s + rbase[0], lse_s + rbase[0], a.lse[0] + ((size_t)b * a.nh + h) * a.L[0], a.L[0], tid, nthr);
         }
-        if (kact[1]) { stage_store<RP>(kimg[1], rk1, tid, nthr); stage_store<RP>(vimg[1], rv1, tid, nthr); }
+        if (kact[1]) { stage_store<RP, DHT>(kimg[1], rk1, tid, nthr); stage_store<RP, DHT>(vimg[1], rv1, tid, nthr); }
         if (qact[1]) {
-            stage_store<RP>(qimg[1], rq1, tid, nthr); stage_store<RP>(gimg[1], rg1, tid, nthr);
-            delta_rows<RP>(rg1, ro1, del_s + rbase[1], lse_s + rbase[1], a.lse[1] + ((size_t)b * a.nh + h) * a.L[1], a.L[1], tid, nthr);
+            stage_store<RP, DHT>(qimg[1], rq1, tid, nthr); stage_store<RP, DHT>(gimg[1], rg1, tid, nthr);
+            delta_rows<RP, DHT>(rg1, ro1, del_s + rbase[1], lse_s + rbase[1], a.lse[1] + ((size_t)b * a.nh + h) * a.L[1], a.L[1], tid, nthr);
         }
-        if (tid == 0) *(int VK_LDS*)(uintptr_t)(lds0 + 4 * ROWS * 128 + 2 * ROWS * 4) = 0;
+        if (tid == 0) *(int VK_LDS*)(uintptr_t)(lds0 + 4 * ROWS * RB + 2 * ROWS * 4) = 0;
     }
     __syncthreads();
 
@@ -319,7 +331,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     // Tasks are claimed from a counter in LDS in the order key tiles (two accumulators: the heavier role) before query tiles, vision
     // before text: 10 tasks of unequal weight on 4 waves in fixed round-robin order left one wave with 4.5 units of work against 3.5 on
     // average.
-    int VK_LDS* const next_task = (int VK_LDS*)(uintptr_t)(lds0 + 4 * ROWS * 128 + 2 * ROWS * 4);
+    int VK_LDS* const next_task = (int VK_LDS*)(uintptr_t)(lds0 + 4 * ROWS * RB + 2 * ROWS * 4);
     (void)nwaves;
     for (;;) {
         int task = 0;
@@ -334,11 +346,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             const int key = kt * 16 + lq;
             const bool kvalid = key < Lk;
             const float kmask = kvalid ? a.mask[mk][(size_t)b * Lk + key] : 0.f;
-            const bf16x8 kf0 = img_row_frag(kimg[mk], kt * 16, 0, lane), kf1 = img_row_frag(kimg[mk], kt * 16, 1, lane);
-            const bf16x8 vf0 = img_row_frag(vimg[mk], kt * 16, 0, lane), vf1 = img_row_frag(vimg[mk], kt * 16, 1, lane);
-            f32x4 dk[4], dv[4];
+            bf16x8 kf[KS], vf[KS];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            for (int ks = 0; ks < KS; ++ks) { kf[ks] = img_row_frag<DHT>(kimg[mk], kt * 16, ks, lane); vf[ks] = img_row_frag<DHT>(vimg[mk], kt * 16, ks, lane); }
+            f32x4 dk[DT], dv[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) { dk[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #define VK_KROLE(MQ)                                                                                       \
             if (a.gate[MQ][mk]) {                                                                          \
                 const int Lq = a.L[MQ];                                                                    \
@@ -353,10 +366,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                             pd[hh] = f32x4{0.f, 0.f, 0.f, 0.f}; ds[hh] = f32x4{0.f, 0.f, 0.f, 0.f};        \
                             if (qt * 16 >= Lq) continue;         /* tile of padding rows only */          \
                             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};                     \
-                            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(qimg[MQ], qt * 16, 0, lane), kf0, s, 0, 0, 0); \
-                            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(qimg[MQ], qt * 16, 1, lane), kf1, s, 0, 0, 0); \
-                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(gimg[MQ], qt * 16, 0, lane), vf0, dp, 0, 0, 0); \
-                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(gimg[MQ], qt * 16, 1, lane), vf1, dp, 0, 0, 0); \
+                            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                            \
+                                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag<DHT>(qimg[MQ], qt * 16, ks, lane), kf[ks], s, 0, 0, 0); \
+                                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag<DHT>(gimg[MQ], qt * 16, ks, lane), vf[ks], dp, 0, 0, 0); \
+                            }                                                                              \
                             /* dropout words: a lane holds one key and needs, for its 4 query rows, word (key & 3) of    */ \
                             /* philox(key >> 2, row).  The 4 lanes of a quad share key >> 2: lane t evaluates row 4g + t */ \
                             /* once and the quad exchanges words (one Philox per lane and tile instead of four).          */ \
@@ -379,9 +392,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                             }                                                                              \
                         }                                                                                  \
                         const bf16x8 pb = pack_pair(pd[0], pd[1]), sb = pack_pair(ds[0], ds[1]);           \
-                        _Pragma("unroll") for (int dt = 0; dt < 4; ++dt) {                                 \
-                            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(gimg[MQ], pp * 32, dt * 16, lane), pb, dv[dt], 0, 0, 0); \
-                            dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(qimg[MQ], pp * 32, dt * 16, lane), sb, dk[dt], 0, 0, 0); \
+                        _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                \
+                            dv[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag<DHT>(gimg[MQ], pp * 32, dt * 16, lane), pb, dv[dt], 0, 0, 0); \
+                            dk[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag<DHT>(qimg[MQ], pp * 32, dt * 16, lane), sb, dk[dt], 0, 0, 0); \
                         }                                                                                  \
                     }                                                                                      \
                 }                                                                                          \
@@ -390,9 +403,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             VK_KROLE(1)
 #undef VK_KROLE
             if (kvalid) {
-                const size_t off = ((size_t)b * Lk + key) * a.ldg[mk] + h * DH + 4 * g;
+                const size_t off = ((size_t)b * Lk + key) * a.ldg[mk] + h * DHT + 4 * g;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) {
+                for (int dt = 0; dt < DT; ++dt) {
                     *(u32x2*)(a.dk[mk] + off + dt * 16) = u32x2{pack2bf(dk[dt][0] * a.scale, dk[dt][1] * a.scale), pack2bf(dk[dt][2] * a.scale, dk[dt][3] * a.scale)};
                     *(u32x2*)(a.dv[mk] + off + dt * 16) = u32x2{pack2bf(dv[dt][0], dv[dt][1]), pack2bf(dv[dt][2], dv[dt][3])};
                 }
@@ -405,13 +418,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             const int Lq = a.L[mq];
             const int qi = qt * 16 + lq;
             const bool qvalid = qi < Lq;
-            const bf16x8 qf0 = img_row_frag(qimg[mq], qt * 16, 0, lane), qf1 = img_row_frag(qimg[mq], qt * 16, 1, lane);
-            const bf16x8 gf0 = img_row_frag(gimg[mq], qt * 16, 0, lane), gf1 = img_row_frag(gimg[mq], qt * 16, 1, lane);
+            bf16x8 qf[KS], gf[KS];
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) { qf[ks] = img_row_frag<DHT>(qimg[mq], qt * 16, ks, lane); gf[ks] = img_row_frag<DHT>(gimg[mq], qt * 16, ks, lane); }
             const float lse = lse_s[rbase[mq] + qt * 16 + lq], delta = del_s[rbase[mq] + qt * 16 + lq];
             const uint32_t drow = (uint32_t)(((size_t)b * a.nh + h) * Lq + (qvalid ? qi : 0));
-            f32x4 dq[4];
+            f32x4 dq[DT];
 #pragma unroll
-            for (int dt = 0; dt < 4; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int dt = 0; dt < DT; ++dt) dq[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #define VK_QROLE(MK)                                                                                       \
             if (a.gate[mq][MK]) {                                                                          \
                 const int Lk = a.L[MK];                                                                    \
@@ -426,10 +440,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                             ds[hh] = f32x4{0.f, 0.f, 0.f, 0.f};                                            \
                             if (kt * 16 >= Lk) continue;         /* tile of padding keys only */          \
                             f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};                     \
-                            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg[MK], kt * 16, 0, lane), qf0, s, 0, 0, 0); \
-                            s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(kimg[MK], kt * 16, 1, lane), qf1, s, 0, 0, 0); \
-                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(vimg[MK], kt * 16, 0, lane), gf0, dp, 0, 0, 0); \
-                            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag(vimg[MK], kt * 16, 1, lane), gf1, dp, 0, 0, 0); \
+                            _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                            \
+                                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag<DHT>(kimg[MK], kt * 16, ks, lane), qf[ks], s, 0, 0, 0); \
+                                dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_row_frag<DHT>(vimg[MK], kt * 16, ks, lane), gf[ks], dp, 0, 0, 0); \
+                            }                                                                              \
                             u32x4 w = {~0u, ~0u, ~0u, ~0u};                                                \
                             if (don) w = philox4((uint32_t)(kt * 4 + g), drow, dc.site, 0u, (uint32_t)seed, (uint32_t)(seed >> 32)); \
                             _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                \
@@ -444,8 +458,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                             }                                                                              \
                         }                                                                                  \
                         const bf16x8 sb = pack_pair(ds[0], ds[1]);                                         \
-                        _Pragma("unroll") for (int dt = 0; dt < 4; ++dt)                                   \
-                            dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag(kimg[MK], pp * 32, dt * 16, lane), sb, dq[dt], 0, 0, 0); \
+                        _Pragma("unroll") for (int dt = 0; dt < DT; ++dt)                                  \
+                            dq[dt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(img_tr_frag<DHT>(kimg[MK], pp * 32, dt * 16, lane), sb, dq[dt], 0, 0, 0); \
                     }                                                                                      \
                 }                                                                                          \
             }
@@ -453,9 +467,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             VK_QROLE(1)
 #undef VK_QROLE
             if (qvalid) {
-                const size_t off = ((size_t)b * Lq + qi) * a.ldg[mq] + h * DH + 4 * g;
+                const size_t off = ((size_t)b * Lq + qi) * a.ldg[mq] + h * DHT + 4 * g;
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt)
+                for (int dt = 0; dt < DT; ++dt)
                     *(u32x2*)(a.dq[mq] + off + dt * 16) = u32x2{pack2bf(dq[dt][0] * a.scale, dq[dt][1] * a.scale), pack2bf(dq[dt][2] * a.scale, dq[dt][3] * a.scale)};
             }
         }
@@ -496,28 +510,33 @@ static int fill(AttnK& k, const vk_attn_args* a, const vk_attn_bwd_args* bw) {
 
 VK_ATTN_TUNABLE g_attn_fwd_waves = 4;    // waves per workgroup (query tiles are looped): 4 workgroups of 4 waves fill the CU's 16 wave slots, one wave per tile (5) leaves it at 3 workgroups (measured -18 %)
 VK_ATTN_TUNABLE g_attn_fwd_occ = 4;      // tuning hook: waves per SIMD the register allocation targets (5 spills 16-74 dwords: slower)
-template <int TP, int RP>
+template <int TP, int RP, int DHT>
 static int launch_fwd(const AttnK& k, int nq_tiles, hipStream_t s) {
-    const int lds = 2 * (TP + RP) * 128 + 16;          // + the task counter
+    const int lds = 2 * (TP + RP) * 2 * DHT + 16;          // + the task counter
     int waves = nq_tiles < 4 ? 4 : (nq_tiles > 8 ? 8 : nq_tiles);      // staging is sized for >= 256 threads
     if (g_attn_fwd_waves >= 4 && g_attn_fwd_waves < waves && 4 * lds <= 160 * 1024) waves = g_attn_fwd_waves;     // only where four workgroups fit the CU's LDS
-    if (g_attn_fwd_occ == 5) hipLaunchKernelGGL((attn_fwd_kernel<TP, RP, 5>), dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
-    else hipLaunchKernelGGL((attn_fwd_kernel<TP, RP, 4>), dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
+    if (DHT == 64 && g_attn_fwd_occ == 5) {
+        hipLaunchKernelGGL((attn_fwd_kernel<TP, RP, 5, DHT>), dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
+    } else {
+        auto kern = attn_fwd_kernel<TP, RP, (DHT == 64 ? 4 : 3), DHT>;      // 128-wide heads: twice the output accumulators, 3 waves per SIMD
+        static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); (void)attr;      // once per process, thread-safe
+        hipLaunchKernelGGL(kern, dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
+    }
     return check_launch("vk_gated_attn_fwd");
 }
 VK_ATTN_TUNABLE g_attn_bwd_waves = 4;    // waves per workgroup (tasks are looped): 4 lets two workgroups share a CU (measured -15 %)
 VK_ATTN_TUNABLE g_attn_bwd_occ = 3;      // waves per SIMD the register allocation targets: 3 (<= 168 VGPRs, a few spilled dwords) lets three 4-wave workgroups share a CU (-3..-9 % against 2)
 
-template <int TP, int RP>
+template <int TP, int RP, int DHT>
 static int launch_bwd(const AttnK& k, int ntasks, hipStream_t s) {
-    const int lds = 4 * (TP + RP) * 128 + 2 * (TP + RP) * 4 + 16;          // + the task counter
-    if (g_attn_bwd_occ == 3 && 3 * lds <= 160 * 1024) {       // three workgroups only fit with the small images
-        auto kern = attn_bwd_kernel<TP, RP, 3>;
+    const int lds = 4 * (TP + RP) * 2 * DHT + 2 * (TP + RP) * 4 + 16;          // + the task counter
+    if (DHT == 64 && g_attn_bwd_occ == 3 && 3 * lds <= 160 * 1024) {       // three workgroups only fit with the small images
+        auto kern = attn_bwd_kernel<TP, RP, 3, DHT>;
         static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); (void)attr;      // once per process, thread-safe
         int waves = g_attn_bwd_waves < 4 ? 4 : (ntasks > g_attn_bwd_waves ? g_attn_bwd_waves : (ntasks < 4 ? 4 : ntasks));
         hipLaunchKernelGGL(kern, dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
     } else {
-        auto kern = attn_bwd_kernel<TP, RP, 2>;
+        auto kern = attn_bwd_kernel<TP, RP, 2, DHT>;
         static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); (void)attr;      // once per process, thread-safe
         int waves = g_attn_bwd_waves < 4 ? 4 : (ntasks > g_attn_bwd_waves ? g_attn_bwd_waves : (ntasks < 4 ? 4 : ntasks));      // staging is sized for >= 256 threads
         hipLaunchKernelGGL(kern, dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
@@ -525,13 +544,31 @@ static int launch_bwd(const AttnK& k, int ntasks, hipStream_t s) {
     return check_launch("vk_gated_attn_bwd");
 }
 
+// LDS of the backward's four images per row (+ statistics): what decides whether 128-wide heads fit the MFMA kernel
+static bool bwd_fits(int TP, int RP, int dht) { return 4 * (TP + RP) * 2 * dht + 2 * (TP + RP) * 4 + 16 <= 160 * 1024; }
+
 }  // namespace vk
 
 namespace vk { int attn_generic(const vk_attn_args* a, const vk_attn_bwd_args* bw, vk_stream_t stream); }      // attention_generic.hip
 
+// Head sizes: 64 (every ctrl_* config) and 128 (config/vilbert_base.json) run on the MFMA kernels above; 128 with the longest sequences
+// (more than 96 padded rows: the backward's images exceed the LDS) and the other sizes (32, 96) on the generic kernels.
+#ifdef VK_STUDY
+static int g_attn_force_generic = 0;      // A/B hook: 128-wide heads on the generic kernels
+extern "C" void vk_attn_set_force_generic(int v) { g_attn_force_generic = v; }
+#else
+static constexpr int g_attn_force_generic = 0;
+#endif
+static bool attn_mfma_ok(const vk_attn_args* a) {
+    if (a->dh == 0 || a->dh == 64) return true;
+    if (a->dh != 128 || g_attn_force_generic) return false;
+    const int TP = a->L[0] > 32 ? 64 : 32, RP = a->L[1] > 64 ? 128 : 64;
+    return vk::bwd_fits(TP, RP, 128);           // forward and backward of one sub-layer take the same path
+}
+
 extern "C" int vk_gated_attn_fwd(const vk_attn_args* a, vk_stream_t stream) {
     using namespace vk;
-    if (a->dh != 0 && a->dh != DH) return attn_generic(a, nullptr, stream);
+    if (!attn_mfma_ok(a)) return attn_generic(a, nullptr, stream);
     AttnK k;
     if (int rc = fill(k, a, nullptr)) return rc;
     if (a->B <= 0) return 0;
@@ -539,15 +576,19 @@ extern "C" int vk_gated_attn_fwd(const vk_attn_args* a, vk_stream_t stream) {
     for (int m = 0; m < 2; ++m) if (a->gate[m][0] || a->gate[m][1]) nq += (a->L[m] + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
     const bool bigT = a->L[0] > 32, bigR = a->L[1] > 64;
-    if (!bigT && !bigR) return launch_fwd<32, 64>(k, nq, s);
-    if (bigT && !bigR) return launch_fwd<64, 64>(k, nq, s);
-    if (!bigT && bigR) return launch_fwd<32, 128>(k, nq, s);
-    return launch_fwd<64, 128>(k, nq, s);
+    if (a->dh == 128) {
+        if (!bigT && !bigR) return launch_fwd<32, 64, 128>(k, nq, s);
+        return launch_fwd<64, 64, 128>(k, nq, s);          // (bigR never fits: attn_mfma_ok)
+    }
+    if (!bigT && !bigR) return launch_fwd<32, 64, 64>(k, nq, s);
+    if (bigT && !bigR) return launch_fwd<64, 64, 64>(k, nq, s);
+    if (!bigT && bigR) return launch_fwd<32, 128, 64>(k, nq, s);
+    return launch_fwd<64, 128, 64>(k, nq, s);
 }
 
 extern "C" int vk_gated_attn_bwd(const vk_attn_args* a, const vk_attn_bwd_args* bw, vk_stream_t stream) {
     using namespace vk;
-    if (a->dh != 0 && a->dh != DH) return attn_generic(a, bw, stream);
+    if (!attn_mfma_ok(a)) return attn_generic(a, bw, stream);
     AttnK k;
     if (int rc = fill(k, a, bw)) return rc;
     if (a->B <= 0) return 0;
@@ -558,10 +599,14 @@ extern "C" int vk_gated_attn_bwd(const vk_attn_args* a, const vk_attn_bwd_args* 
     }
     hipStream_t s = (hipStream_t)stream;
     const bool bigT = a->L[0] > 32, bigR = a->L[1] > 64;
-    if (!bigT && !bigR) return launch_bwd<32, 64>(k, nt, s);
-    if (bigT && !bigR) return launch_bwd<64, 64>(k, nt, s);
-    if (!bigT && bigR) return launch_bwd<32, 128>(k, nt, s);
-    return launch_bwd<64, 128>(k, nt, s);
+    if (a->dh == 128) {
+        if (!bigT && !bigR) return launch_bwd<32, 64, 128>(k, nt, s);
+        return launch_bwd<64, 64, 128>(k, nt, s);
+    }
+    if (!bigT && !bigR) return launch_bwd<32, 64, 64>(k, nt, s);
+    if (bigT && !bigR) return launch_bwd<64, 64, 64>(k, nt, s);
+    if (!bigT && bigR) return launch_bwd<32, 128, 64>(k, nt, s);
+    return launch_bwd<64, 128, 64>(k, nt, s);
 }
 #ifdef VK_STUDY
 extern "C" void vk_attn_set_bwd_occupancy(int v) { vk::g_attn_bwd_occ = v; }
