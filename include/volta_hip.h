@@ -9,6 +9,7 @@
  */
 #ifndef VOLTA_HIP_H
 #define VOLTA_HIP_H
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -320,6 +321,10 @@ int vk_text_end_rows(const int64_t* ids, int B, int T, int32_t* rows, int32_t* c
 /* VL-BERT with the xent_1601 target gives masked regions (all-zero feature rows) a word of their own (embeddings.py:191,262-264):
    ids[m] = 1 for the last region of a sample (END), 2 for a masked region, 0 otherwise -- the row of the 3-row word table. */
 int vk_vlbert_obj_ids(const int32_t* zero_flag, int64_t* ids, int M, int K, vk_stream_t s);
+/* VL-BERT's position ids (embeddings.py:278-292) from input_ids [B, T] (0 = pad), K boxes per sample:
+   text_end[b] = #non-zero ids; tpos[b, t] = t + (t >= min_b text_end[b] ? K : 0) (the reference's shift goes through a stride-0
+   expanded view, so it lands in the row all samples share); opos[b, k] = text_end[b] + (k == K - 1). */
+int vk_vlbert_positions(const int64_t* ids, int B, int T, int K, int64_t* tpos, int64_t* opos, vk_stream_t s);
 
 /* ------------------------------------------------------------------------------------------------
  * The visual targets other than kl_1601 (volta/losses.py:25-126), on the labelled regions only.  Row i of `logits` is the
@@ -452,7 +457,8 @@ enum {
     VK_FN_VIS_LOSS_BWD,  /* vk_vis_loss_bwd(p[0], p[1], n[0], p[2]) */
     VK_FN_NCE_NEG,       /* vk_nce_negatives(drop, n[0], n[1], p[0]) */
     VK_FN_TEXT_END_ROWS, /* vk_text_end_rows(p[0], n[0], n[1], p[1], p[2]) */
-    VK_FN_VLBERT_OBJ_IDS /* vk_vlbert_obj_ids(p[0], p[1], n[0], n[1]) */
+    VK_FN_VLBERT_OBJ_IDS, /* vk_vlbert_obj_ids(p[0], p[1], n[0], n[1]) */
+    VK_FN_VLBERT_POSITIONS /* vk_vlbert_positions(p[0], n[0], n[1], n[2], p[1], p[2]) */
 };                       /* VK_FN_POOL_FWD / VK_FN_POOL_BWD: n[3] = fusion mode (VK_FUSE_*) */
 typedef struct vk_generic_args {   /* positional arguments of the small entry points, see executor.cpp */
     int32_t fn;
@@ -509,6 +515,52 @@ typedef struct vk_concap_args {
     int32_t objective;           /* 0, 1 (mismatched pairs lose their MLM / region labels), 2 (no swaps) */
 } vk_concap_args;
 int vk_concap_batch(const vk_concap_args* a, vk_stream_t s);
+
+/* ------------------------------------------------------------------------------------------------
+ * Record readers in front of the batch producer.  Host code (no stream argument): files are memory-mapped and fields
+ * are decoded straight into the caller's staging slot -- use pinned memory and one cudaMemcpyAsync per batch.
+ *
+ * vk_lmdb_*: read-only access to an LMDB data file, replacing `lmdb.open(path, readonly=True, lock=False)` + `txn.get` / cursor iteration
+ * (volta/datasets/_image_features_reader.py:46-58,83; tensorpack's LMDBSerializer.load at concept_cap_dataset.py:117-121,305-309).
+ * `path` is the data file or the directory holding `data.mdb`.  Returned key / value pointers point into the mapping and stay valid
+ * until vk_lmdb_close.  Main database only; DUPSORT / named sub-databases are refused. */
+typedef struct vk_lmdb vk_lmdb;
+int vk_lmdb_open(const char* path, vk_lmdb** out);
+void vk_lmdb_close(vk_lmdb* db);
+int64_t vk_lmdb_entries(const vk_lmdb* db);
+int vk_lmdb_first(vk_lmdb* db);                                   /* rewind the cursor to the smallest key */
+/* 1 = record returned and cursor advanced (keys in memcmp order), 0 = end, -1 = error */
+int vk_lmdb_next(vk_lmdb* db, const void** key, size_t* klen, const void** val, size_t* vlen);
+/* 1 = found, 0 = no such key, -1 = error */
+int vk_lmdb_get(const vk_lmdb* db, const void* key, size_t klen, const void** val, size_t* vlen);
+
+/* One Conceptual Captions datapoint = msgpack array of the 13 fields BertPreprocessBatch.__call__ unpacks (concept_cap_dataset.py:430-431):
+ * features [nb, F], cls_prob [nb, C], obj_labels [nb], obj_confs [nb], attr_labels [nb], attr_confs [nb], attr_scores [nb, A], boxes [nb, 4],
+ * num_boxes, img_h, img_w, img_id, caption; ndarrays in msgpack_numpy's encoding ({nd, type, kind, shape, data}).  Decodes into one slot of
+ * the staging arrays vk_concap_batch reads: rows >= num_boxes are zero-filled (the reference stages into np.zeros, :433-446); a record with
+ * more than R boxes is an error (the reference's assignment raises).  NULL destinations are skipped. */
+typedef struct vk_concap_record {
+    float* feat;            /* [R, F] */
+    float* cls;             /* [R, C] */
+    float* attr;            /* [R, A] or NULL */
+    float* boxes;           /* [R, 4] pixels */
+    int64_t* obj_labels;    /* [R] or NULL */
+    float* obj_confs;       /* [R] or NULL */
+    int64_t* attr_labels;   /* [R] or NULL */
+    float* attr_confs;      /* [R] or NULL */
+    int32_t R, F, C, A;
+    int32_t num_boxes;      /* out */
+    float img_w, img_h;     /* out */
+    int32_t caption_len;    /* out */
+    const char* caption;    /* out: UTF-8 bytes inside the record (not NUL-terminated) */
+    char image_id[64];      /* out: NUL-terminated */
+} vk_concap_record;
+int vk_concap_record_decode(const void* rec, size_t len, vk_concap_record* r);
+
+/* base64 text (standard or url-safe alphabet, padding optional, line breaks skipped) -> bytes: the `boxes` / `features` / `cls_prob`
+ * columns of the extraction TSV (data/conceptual_captions/preprocess_cc_train.py:66-68) and of the task feature stores
+ * (_image_features_reader.py:87-88). */
+int vk_b64_decode(const char* src, size_t n, void* dst, size_t cap, size_t* out_len);
 
 #ifdef __cplusplus
 }

@@ -159,3 +159,28 @@ def test_text_end_rows_and_vlbert_word_ids():
     torch.cuda.synchronize()
     want = torch.where(torch.arange(M) % K == K - 1, 1, torch.where(z == 1, 2, 0))
     assert torch.equal(out.cpu(), want.long())
+
+
+@pytest.mark.parametrize("B,T,K", [(7, 20, 9), (1, 5, 2), (1100, 38, 37), (3, 16, 101)])
+def test_vlbert_position_ids(B, T, K):
+    """vk_vlbert_positions against the oracle's statement of embeddings.py:278-292 (the stride-0 shift quirk included):
+    ragged captions, one full-length caption, an all-pad caption, more samples than the work-group has threads."""
+    L = _lib()
+    g = torch.Generator().manual_seed(B + T)
+    lens = torch.randint(2, T + 1, (B,), generator=g)
+    lens[0] = T
+    if B > 2:
+        lens[1], lens[2] = 0, 2
+    ids = torch.randint(1, 3000, (B, T), generator=g) * (torch.arange(T)[None] < lens[:, None])
+    idc = ids.cuda()
+    tpos = torch.full((B, T), -1, dtype=torch.int64, device="cuda")
+    opos = torch.full((B, K), -1, dtype=torch.int64, device="cuda")
+    L.check(L.lib.vk_vlbert_positions(C.c_void_p(idc.data_ptr()), B, T, K, C.c_void_p(tpos.data_ptr()), C.c_void_p(opos.data_ptr()), L.stream_ptr()))
+    torch.cuda.synchronize()
+    text_end = (ids != 0).sum(1, keepdim=True)
+    ar = torch.arange(T)
+    shifted = (ar[None] >= text_end).any(0)
+    want_t = (ar + K * shifted.long())[None].expand(B, T)
+    want_o = text_end.expand(B, K).clone()
+    want_o[:, -1] += 1
+    assert torch.equal(tpos.cpu(), want_t) and torch.equal(opos.cpu(), want_o)

@@ -80,6 +80,12 @@ class ConcapArgs(C.Structure):
                                                             "add_global", "objective")]
 
 
+class ConcapRecord(C.Structure):
+    _fields_ = [(n, c_p) for n in ("feat", "cls", "attr", "boxes", "obj_labels", "obj_confs", "attr_labels", "attr_confs")] + \
+               [(n, i32) for n in ("R", "F", "C", "A", "num_boxes")] + [("img_w", C.c_float), ("img_h", C.c_float), ("caption_len", i32),
+                                                                        ("caption", c_p), ("image_id", C.c_char * 64)]
+
+
 class EmbedArgs(C.Structure):
     _fields_ = [("ids", c_p), ("type_ids", c_p), ("pos_ids", c_p), ("word", c_p), ("pos", c_p), ("type", c_p),
                 ("extra", c_p), ("z", c_p), ("M", i32), ("T", i32), ("H", i32), ("V", i32), ("P", i32), ("n_types", i32)]
@@ -139,7 +145,7 @@ class Op(C.Structure):
 (FN_CAST, FN_MEMSET, FN_LOC_FWD, FN_LOC_BWD, FN_ADD_DROPOUT, FN_COLSUM, FN_SELECT, FN_GATHER, FN_SCATTER_ADD,
  FN_LOSS_FINAL, FN_POOL_FWD, FN_POOL_BWD, FN_MASK_PREP, FN_MUL, FN_VLBERT_PREP, FN_VLBERT_MASKGRAD, FN_ROWGROUP_SUM,
  FN_RELU_BWD, FN_COPY, FN_SUM_SLABS, FN_SUM_SLABS_BF16, FN_SIDE_TAIL, FN_QUANT_ROWS, FN_CAST_FP8, FN_VIS_LOSS_FWD, FN_VIS_LOSS_BWD,
- FN_NCE_NEG, FN_TEXT_END_ROWS, FN_VLBERT_OBJ_IDS) = range(1, 30)
+ FN_NCE_NEG, FN_TEXT_END_ROWS, FN_VLBERT_OBJ_IDS, FN_VLBERT_POSITIONS) = range(1, 31)
 
 
 class AttnArgs(C.Structure):
@@ -203,6 +209,15 @@ _sig("vk_pool_fuse_fwd", C.c_int, c_p, c_p, c_p, C.c_int, C.c_int, C.c_int, Drop
 _sig("vk_pool_fuse_bwd", C.c_int, c_p, C.c_int, c_p, c_p, c_p, c_p, C.c_int, C.c_int, C.c_int, Dropout, c_p)
 _sig("vk_text_end_rows", C.c_int, c_p, C.c_int, C.c_int, c_p, c_p, c_p)
 _sig("vk_vlbert_obj_ids", C.c_int, c_p, c_p, C.c_int, C.c_int, c_p)
+_sig("vk_lmdb_open", C.c_int, C.c_char_p, C.POINTER(c_p))
+_sig("vk_lmdb_close", None, c_p)
+_sig("vk_lmdb_entries", C.c_int64, c_p)
+_sig("vk_lmdb_first", C.c_int, c_p)
+_sig("vk_lmdb_next", C.c_int, c_p, C.POINTER(c_p), C.POINTER(C.c_size_t), C.POINTER(c_p), C.POINTER(C.c_size_t))
+_sig("vk_lmdb_get", C.c_int, c_p, C.c_char_p, C.c_size_t, C.POINTER(c_p), C.POINTER(C.c_size_t))
+_sig("vk_concap_record_decode", C.c_int, c_p, C.c_size_t, C.POINTER(ConcapRecord))
+_sig("vk_b64_decode", C.c_int, C.c_char_p, C.c_size_t, c_p, C.c_size_t, C.POINTER(C.c_size_t))
+_sig("vk_vlbert_positions", C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, c_p, c_p)
 _sig("vk_vis_loss_fwd", C.c_int, C.POINTER(VisLossArgs), c_p)
 _sig("vk_vis_loss_bwd", C.c_int, C.POINTER(VisLossArgs), c_p, C.c_int, c_p, c_p)
 _sig("vk_nce_negatives", C.c_int, Dropout, C.c_int, C.c_int, c_p, c_p)
@@ -234,9 +249,10 @@ EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_c
            "vk_add_dropout", "vk_colsum_bf16", "vk_vlbert_prep_fwd", "vk_vlbert_maskgrad", "vk_rowgroup_sum_bf16",
            "vk_relu_bwd_bf16", "vk_copy_async", "vk_select_rows", "vk_gather_rows", "vk_scatter_rows_add", "vk_xent_fwd",
            "vk_xent_bwd", "vk_kl_fwd", "vk_kl_bwd", "vk_loss_finalize", "vk_pool_mul_fwd", "vk_pool_mul_bwd",
-           "vk_pool_fuse_fwd", "vk_pool_fuse_bwd", "vk_text_end_rows", "vk_vlbert_obj_ids", "vk_vis_loss_fwd", "vk_vis_loss_bwd", "vk_nce_negatives",
+           "vk_pool_fuse_fwd", "vk_pool_fuse_bwd", "vk_text_end_rows", "vk_vlbert_obj_ids", "vk_vlbert_positions", "vk_vis_loss_fwd", "vk_vis_loss_bwd", "vk_nce_negatives",
            "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_grad_norm_clip_masked", "vk_adamw_step",
-           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_side_tail", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_join_from", "vk_side_enable", "vk_concap_batch"]
+           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_side_tail", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_join_from", "vk_side_enable", "vk_concap_batch",
+           "vk_lmdb_open", "vk_lmdb_close", "vk_lmdb_entries", "vk_lmdb_first", "vk_lmdb_next", "vk_lmdb_get", "vk_concap_record_decode", "vk_b64_decode"]
 
 
 def check(rc):

@@ -165,6 +165,7 @@ static int run_one(const vk_op& o, int i, vk_stream_t s) {
                     case VK_FN_NCE_NEG: rc = vk_nce_negatives(g->drop, (int)g->n[0], (int)g->n[1], (int32_t*)g->p[0], s); break;
                     case VK_FN_TEXT_END_ROWS: rc = vk_text_end_rows((const int64_t*)g->p[0], (int)g->n[0], (int)g->n[1], (int32_t*)g->p[1], (int32_t*)g->p[2], s); break;
                     case VK_FN_VLBERT_OBJ_IDS: rc = vk_vlbert_obj_ids((const int32_t*)g->p[0], (int64_t*)g->p[1], (int)g->n[0], (int)g->n[1], s); break;
+                    case VK_FN_VLBERT_POSITIONS: rc = vk_vlbert_positions((const int64_t*)g->p[0], (int)g->n[0], (int)g->n[1], (int)g->n[2], (int64_t*)g->p[1], (int64_t*)g->p[2], s); break;
                     case VK_FN_MASK_PREP: rc = vk_mask_prep((const int64_t*)g->p[0], (float*)g->p[1], (int)g->n[0], s); break;
                     case VK_FN_MUL: rc = vk_mul_bf16(g->p[0], g->p[1], g->p[2], g->n[0], (const int32_t*)g->p[3], (int)g->n[1], s); break;
                     case VK_FN_VLBERT_PREP: rc = vk_vlbert_prep_fwd((const float*)g->p[0], (int)g->n[3], (const float*)g->p[1], (const float*)g->p[2], g->p[3], (int32_t*)g->p[4], (int)g->n[0], (int)g->n[1], (int)g->n[2], g->drop, s); break;

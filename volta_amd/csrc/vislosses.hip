@@ -237,6 +237,31 @@ __global__ void vlbert_obj_ids_kernel(const int32_t* zero_flag, int64_t* ids, in
     if (m < M) ids[m] = (m % K == K - 1) ? 1 : (zero_flag[m] ? 2 : 0);
 }
 
+// VL-BERT's position ids (volta/embeddings.py:278-292): text_end[b] = number of non-pad tokens.  Text position t is t, plus K wherever
+// ANY sample has t >= its text_end (the reference writes the shift through a stride-0 expanded view, so it lands in the one row every
+// sample shares): that is t >= min_b text_end[b].  Every box of sample b sits at text_end[b], the last one at text_end[b] + 1.
+// One work-group: B * (2T + K) integer operations.
+__global__ __launch_bounds__(1024) void vlbert_positions_kernel(const int64_t* ids, int B, int T, int K, int64_t* tpos, int64_t* opos) {
+    __shared__ int s_min[16];
+    const int tid = threadIdx.x;
+    int lo = T;
+    for (int b = tid; b < B; b += 1024) {
+        int c = 0;
+        for (int t = 0; t < T; ++t) c += ids[(size_t)b * T + t] != 0;
+        lo = min(lo, c);
+        for (int k = 0; k < K; ++k) opos[(size_t)b * K + k] = c + (k == K - 1);
+    }
+    for (int o = 32; o; o >>= 1) lo = min(lo, __shfl_xor(lo, o));
+    if ((tid & 63) == 0) s_min[tid >> 6] = lo;
+    __syncthreads();
+    lo = s_min[0];
+    for (int w = 1; w < 16; ++w) lo = min(lo, s_min[w]);
+    for (int i = tid; i < B * T; i += 1024) {
+        const int t = i % T;
+        tpos[i] = t + (t >= lo ? K : 0);
+    }
+}
+
 }  // namespace vk
 
 using namespace vk;
@@ -309,4 +334,10 @@ extern "C" int vk_vlbert_obj_ids(const int32_t* zero_flag, int64_t* ids, int M, 
     if (M <= 0 || K <= 0) return set_error("vk_vlbert_obj_ids: bad arguments");
     hipLaunchKernelGGL(vlbert_obj_ids_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)s, zero_flag, ids, M, K);
     return check_launch("vk_vlbert_obj_ids");
+}
+
+extern "C" int vk_vlbert_positions(const int64_t* ids, int B, int T, int K, int64_t* tpos, int64_t* opos, vk_stream_t s) {
+    if (B <= 0 || T <= 0 || K <= 0 || !ids || !tpos || !opos) return set_error("vk_vlbert_positions: bad arguments");
+    hipLaunchKernelGGL(vlbert_positions_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, ids, B, T, K, tpos, opos);
+    return check_launch("vk_vlbert_positions");
 }

@@ -655,9 +655,14 @@ class StepEngine:
         self.patch("token_type_ids", ea, "type_ids")
         f.append((L.OP_EMBED_FWD, 0, 0, 0, ea, None, None))
         proj, featb = self._img_proj(pre, "projection", "emb_v")
-        # addvec = position_embeddings_visual[0] + token_type_embeddings_visual[1], rebuilt every step (2 tiny ops)
+        # addvec = position_embeddings_visual[0] + token_type_embeddings_visual[1], rebuilt every step by one list op: the two rows are
+        # two "slabs" of the fp32 master arena, a fixed distance apart
         vec = self.buf("emb_v_addvec", (H,), torch.float32)
-        self._visualbert_vec = (vec, pre)
+        rows = sorted((self.Pm(pre + "position_embeddings_visual.weight")[0], self.Pm(pre + "token_type_embeddings_visual.weight")[1]), key=lambda r: r.data_ptr())
+        gap = rows[1].data_ptr() - rows[0].data_ptr()
+        if gap % 16:
+            raise NotImplementedError("hidden size must be a multiple of 4")
+        f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SUM_SLABS, p=(vec, rows[0]), n=(gap // 4, 2, H)), None, None))
         yt, yv = self.buf("emb_t_y", (st_t.M, H)), self.buf("emb_v_y", (st_v.M, H))
         zv = self.buf("emb_v_z", (st_v.M, H))
         stats = [self.buf("emb_%s" % s, (m,), torch.float32) for s, m in (("t_mean", st_t.M), ("t_rstd", st_t.M), ("v_mean", st_v.M), ("v_rstd", st_v.M))]
@@ -717,8 +722,12 @@ class StepEngine:
         self.bufs["vl_cntMt"] = cntMt = torch.tensor([st_t.M], device=dev, dtype=torch.int32)
         vtab = self.buf("vl_vtab", (nword, H), torch.float32)       # rows: object word, END word (last region), masked-region word
         dvtab = self.buf("vl_dvtab", (nword, H), torch.float32)
-        self._vlbert = dict(pre=pre, tpos=tpos, opos=opos, vtab=vtab, T=T, K=K, mvrc=mvrc)
-        # ---- forward
+        # ---- forward: position ids from this step's input_ids, and the (object | END | masked) word table from the parameters
+        g = self.generic(L.FN_VLBERT_POSITIONS, p=(None, tpos, opos), n=(B, T, K))
+        self.patch("input_ids", g, "p", 0)
+        f.append((L.OP_GENERIC, 0, 0, 0, g, None, None))
+        for r, nm in enumerate(("object_linguistic_embeddings", "end_embedding", "object_mask_word_embedding")[:nword]):
+            f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_COPY, p=(vtab[r], self.Pm(pre + nm + ".weight")[0]), n=(H * 4,)), None, None))
         x4 = self.buf("vl_x4096", (st_v.M, W))
         zflag = self.buf("vl_zero_flag", (st_v.M,), torch.int32)
         dr0 = self.drop(cfg.v_attention_probs_dropout_prob)
@@ -1539,38 +1548,6 @@ class StepEngine:
     def prepare_step(self, seed):
         if self.train or getattr(self, "nce_site", None) is not None:      # nce_2048 draws its negatives in eval mode too
             check(L.lib.vk_set_seed(ptr(self.seed), C.c_uint64(seed & 0xFFFFFFFFFFFFFFFF), L.stream_ptr()))
-        vl = getattr(self, "_vlbert", None)
-        if vl is not None:
-            self._vlbert_positions(vl)
-        v = getattr(self, "_visualbert_vec", None)
-        if v is not None:
-            vec, pre = v
-            torch.add(self.Pm(pre + "position_embeddings_visual.weight")[0], self.Pm(pre + "token_type_embeddings_visual.weight")[1], out=vec)
-
-
-def _vlbert_positions(self, vl):
-    """Position ids of VL-BERT (volta/embeddings.py:278-292) from the step's input_ids, with device-side torch ops (no
-    host sync): text_end = number of non-pad tokens; text positions are arange(T), shifted by the number of boxes
-    wherever ANY sample of the batch has t >= its text_end (the reference applies the shift through an expanded,
-    stride-0 view, so it lands in the row shared by every sample -- kept, the oracle documents it); every box sits at
-    text_end, the last one at text_end + 1.  Also refreshes the 2-row (object | END) embedding table."""
-    ids = self._cur_inputs["input_ids"]
-    B, T, K = ids.shape[0], vl["T"], vl["K"]
-    text_end = (ids != 0).sum(1, keepdim=True)
-    ar = torch.arange(T, device=ids.device)
-    shifted = (ar[None] >= text_end).any(0)
-    vl["tpos"].view(B, T).copy_((ar + K * shifted.long())[None].expand(B, T))
-    op = vl["opos"].view(B, K)
-    op.copy_(text_end.expand(B, K))
-    op[:, -1] += 1
-    pre = vl["pre"]
-    vl["vtab"][0].copy_(self.Pm(pre + "object_linguistic_embeddings.weight")[0])
-    vl["vtab"][1].copy_(self.Pm(pre + "end_embedding.weight")[0])
-    if vl.get("mvrc"):
-        vl["vtab"][2].copy_(self.Pm(pre + "object_mask_word_embedding.weight")[0])
-
-
-StepEngine._vlbert_positions = _vlbert_positions
 
 
 def _mk_segs(drop, segs):

@@ -377,7 +377,7 @@ class BertForVLPreTraining(PreTrainedModel):
     def _engine_backward(self, g_lm, g_img, g_nsp):
         eng, tensors = self._last
         state = self._backward_begin(eng)
-        eng.gout.copy_(torch.cat([g_lm.reshape(1), g_img.reshape(1), g_nsp.reshape(1)]).to(eng.gout))
+        torch.cat([g_lm.reshape(1), g_img.reshape(1), g_nsp.reshape(1)], out=eng.gout)      # one launch, no temporary
         self._backward_run(eng, state)
 
     def _backward_begin(self, eng):
