@@ -556,6 +556,9 @@ typedef struct vk_concap_record {
     char image_id[64];      /* out: NUL-terminated */
 } vk_concap_record;
 int vk_concap_record_decode(const void* rec, size_t len, vk_concap_record* r);
+/* n datapoints into n slots on `threads` host threads (records are independent).  -1 with the first failing record's message;
+   *failed (optional) = its index. */
+int vk_concap_records_decode(const void* const* recs, const size_t* lens, vk_concap_record* slots, int n, int threads, int* failed);
 
 /* base64 text (standard or url-safe alphabet, padding optional, line breaks skipped) -> bytes: the `boxes` / `features` / `cls_prob`
  * columns of the extraction TSV (data/conceptual_captions/preprocess_cc_train.py:66-68) and of the task feature stores

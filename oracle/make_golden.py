@@ -526,6 +526,69 @@ def write_concap():
           "masked regions", int((o["image_label"] == 1).sum()), os.path.getsize(path) // 1024, "KB")
 
 
+
+def feature_store_records(seed=11, n_images=4, F=16):
+    """Per-image records of a task feature store (what data/*/convert_*_lmdb.py pickles: the TSV row, every field a string): shared with the tests."""
+    import base64
+    rng = np.random.default_rng(seed)
+    recs = {}
+    for i in range(n_images):
+        n = int(rng.integers(2, 9))
+        w, h = int(rng.integers(300, 800)), int(rng.integers(300, 800))
+        xy = rng.uniform(0, 0.6, (n, 2)) * np.array([w, h])
+        wh = rng.uniform(0.1, 0.4, (n, 2)) * np.array([w, h])
+        boxes = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        feats = rng.standard_normal((n, F)).astype(np.float32)
+        recs[str(1000 + 37 * i)] = dict(img_id=str(1000 + 37 * i), img_h=str(h), img_w=str(w), num_boxes=str(n),
+                                        boxes=base64.b64encode(boxes.tobytes()).decode(), features=base64.b64encode(feats.tobytes()).decode())
+    return recs
+
+
+def write_feature_reader():
+    """The REAL ImageFeaturesH5Reader.__getitem__ (volta/datasets/_image_features_reader.py:69-196) on a small synthetic store, served by a
+    dict-backed stand-in for the `lmdb` module (the container; `vk_lmdb_*` replaces it and is tested on files written by tests/lmdb_writer.py).
+    Pins the box normalisation, the area column, the global feature / box rows and the dtypes numpy's promotions leave behind."""
+    import importlib.util, pickle
+    recs = feature_store_records()
+    store = {k.encode(): pickle.dumps(v) for k, v in recs.items()}
+    store[b"keys"] = pickle.dumps([k.encode() for k in recs])
+
+    class Txn:
+        def __enter__(self): return self
+        def __exit__(self, *a): return False
+        def get(self, key): return store.get(key)
+
+    fake = types.ModuleType("lmdb")
+    fake.open = lambda *a, **k: types.SimpleNamespace(begin=lambda write=False: Txn())
+    saved = sys.modules.get("lmdb")
+    sys.modules["lmdb"] = fake
+    try:
+        spec = importlib.util.spec_from_file_location("ref_feature_reader", os.path.join(REF, "volta", "datasets", "_image_features_reader.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+    finally:
+        if saved is None:
+            del sys.modules["lmdb"]
+        else:
+            sys.modules["lmdb"] = saved
+    blob = {}
+    for nl in (4, 5):
+        for glob in (None, "first", "last"):
+            for mem in (False, True):
+                cfg = types.SimpleNamespace(v_feature_size=16, num_locs=nl, add_global_imgfeat=glob)
+                rd = mod.ImageFeaturesH5Reader("unused", cfg, in_memory=mem)
+                assert len(rd) == len(recs)
+                for k in recs:
+                    f, n, loc, ori = rd[k]
+                    if mem:
+                        f, n, loc, ori = rd[k]          # second read comes from the in-memory copy
+                    tag = "l%d_%s_%d_%s" % (nl, glob, mem, k)
+                    blob[tag + "_features"], blob[tag + "_num"], blob[tag + "_loc"], blob[tag + "_ori"] = f, np.array(n), np.asarray(loc), np.asarray(ori)
+    path = os.path.join(OUT, "feature_reader.npz")
+    np.savez_compressed(path, **blob)
+    print("feature_reader", len(blob), "arrays", {str(v.dtype) for v in blob.values()}, os.path.getsize(path) // 1024, "KB")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -548,3 +611,5 @@ if __name__ == "__main__":
         write_tasks(BertConfig)
     if which in ("all", "concap"):
         write_concap()
+    if which in ("all", "reader"):
+        write_feature_reader()

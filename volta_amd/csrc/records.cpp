@@ -17,8 +17,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <string>
+#include <thread>
 #include <type_traits>
+#include <vector>
 
 #include "util.h"
 #include "volta_hip.h"
@@ -546,4 +549,40 @@ extern "C" int vk_concap_record_decode(const void* rec, size_t len, vk_concap_re
     r->caption = (const char*)cv.s;
     r->caption_len = (int32_t)cv.n;
     return 0;
+}
+
+// A batch of datapoints on `threads` host threads (the decoder shares nothing: every record has its own slot).  Returns 0 or -1 with the
+// message of the first record that failed; `failed` (optional) receives that record's index.
+extern "C" int vk_concap_records_decode(const void* const* recs, const size_t* lens, vk_concap_record* slots, int n, int threads, int* failed) {
+    if (n <= 0) return 0;
+    if (!recs || !lens || !slots) return set_error("vk_concap_records_decode: null argument");
+    if (threads < 1) threads = 1;
+    if (threads > n) threads = n;
+    if (failed) *failed = -1;
+    if (threads == 1) {
+        for (int i = 0; i < n; ++i)
+            if (vk_concap_record_decode(recs[i], lens[i], &slots[i])) {
+                if (failed) *failed = i;
+                return -1;
+            }
+        return 0;
+    }
+    std::atomic<int> next{0}, bad{n};
+    std::vector<std::string> msg((size_t)threads);
+    auto work = [&](int t) {
+        for (int i = next.fetch_add(1); i < n; i = next.fetch_add(1)) {
+            if (vk_concap_record_decode(recs[i], lens[i], &slots[i]) == 0) continue;
+            int cur = bad.load();
+            while (i < cur && !bad.compare_exchange_weak(cur, i)) {}
+            if (i <= bad.load()) msg[(size_t)t] = vk_last_error();      // the error text is thread-local: carry it to the caller's thread
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& th : pool) th.join();
+    if (bad.load() == n) return 0;
+    if (failed) *failed = bad.load();
+    // re-run the failing record on this thread: deterministic, and leaves its message in this thread's vk_last_error()
+    return vk_concap_record_decode(recs[bad.load()], lens[bad.load()], &slots[bad.load()]) ? -1 : set_error("vk_concap_records_decode: record %d failed", bad.load());
 }

@@ -63,18 +63,21 @@ class ConceptCapBatchProducer:
     (pixels), `num_boxes [B]`, `img_wh [B, 2]`, `cap_index [B]`.  One call = three HIP launches (csrc/concap.hip)."""
 
     def __init__(self, captions, seq_len, region_len, vocab_size, add_global_imgfeat="first", objective=1, cls_id=101, sep_id=102, mask_id=103,
-                 device="cuda"):
+                 device="cuda", extra_rows=0, min_ld=0, n_random=None):
+        """`extra_rows` empty rows behind the corpus (a loader writes each batch's own captions there and points `cap_index` at them);
+        `n_random`: replacement captions are drawn from rows [0, n_random) (default: all of `captions`)."""
         from . import _lib as L
         self.L = L
         self.T, self.R, self.V = int(seq_len), int(region_len), int(vocab_size)
         self.add_global = {None: 0, "first": 1, "last": 2}[add_global_imgfeat]
         self.objective, self.ids = int(objective), (int(cls_id), int(sep_id), int(mask_id))
-        ld = max(1, max(len(c) for c in captions))
-        tok = torch.zeros(len(captions), ld, dtype=torch.int32)
+        ld = max(1, int(min_ld), max((len(c) for c in captions), default=1))
+        tok = torch.zeros(len(captions) + int(extra_rows), ld, dtype=torch.int32)
         for i, c in enumerate(captions):
             tok[i, :len(c)] = torch.tensor(c, dtype=torch.int32)
         self.cap_tokens = tok.to(device)
-        self.cap_len = torch.tensor([len(c) for c in captions], dtype=torch.int32, device=device)
+        self.cap_len = torch.tensor([len(c) for c in captions] + [0] * int(extra_rows), dtype=torch.int32, device=device)
+        self.n_random = len(captions) if n_random is None else int(n_random)
         self.device = device
 
     def __call__(self, feat, cls, boxes, num_boxes, img_wh, cap_index, seed):
@@ -95,7 +98,7 @@ class ConceptCapBatchProducer:
         a = L.ConcapArgs(L.ptr(self.cap_tokens), L.ptr(self.cap_len), L.ptr(keep[5]), L.ptr(keep[0]), L.ptr(keep[1]), L.ptr(keep[2]), L.ptr(keep[3]),
                          L.ptr(keep[4]), *[L.ptr(out[k]) for k in ("input_ids", "input_mask", "segment_ids", "lm_label_ids", "is_match", "image_feat",
                                                                     "image_loc", "image_cls", "image_label", "image_mask")],
-                         C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), B, self.T, R, F, Cn, self.cap_tokens.shape[0], self.cap_tokens.shape[1], self.V,
+                         C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), B, self.T, R, F, Cn, self.n_random, self.cap_tokens.shape[1], self.V,
                          self.ids[0], self.ids[1], self.ids[2], self.add_global, self.objective)
         L.check(L.lib.vk_concap_batch(C.byref(a), L.stream_ptr()))
         out["_keep"] = keep          # inputs stay alive until the stream has consumed them
