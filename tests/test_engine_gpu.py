@@ -201,3 +201,31 @@ def test_backward_is_reproducible_back_to_back(name):
             off, numel = arena.offset[n], arena.view(n, "grad").numel()
             scale = float(snaps[0][off:off + numel].abs().max())
             assert float(d[off:off + numel].max()) <= 1e-4 * max(scale, 1e-3), (r, n, float(d[off:off + numel].max()), scale)
+
+
+@pytest.mark.parametrize("name", ["vilbert", "uniter"])
+def test_bert_model_returns_every_sublayer_state(name):
+    """`model.bert(..., output_all_encoded_layers=True)` (volta/encoders.py:868-881, 1013-1017): one entry per sub-layer for BOTH streams
+    (a stream a sub-layer does not touch repeats its state), each against the oracle's state after that sub-layer; the last entry is what the
+    call returns without the flag."""
+    from oracle import volta_ref as R
+    from volta_amd.modules import sublayer_schedule
+    model, rcfg, sd = build(name)
+    model.eval()
+    batch = R.synthetic_batch(rcfg, 4, 20, 36, seed=7, pad=True)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    args = (cb["input_ids"], cb["image_feat"], cb["image_loc"], cb["segment_ids"], cb["input_mask"], cb["image_mask"])
+    seq_t, seq_v, pooled_t, pooled_v, maps = model.bert(*args, output_all_encoded_layers=True)
+    last_t, last_v, pt2, pv2, _ = model.bert(*args)
+    ids = [n for n, _ in sublayer_schedule(model.config)]
+    assert isinstance(seq_t, list) and len(seq_t) == len(seq_v) == len(ids) and maps == ([], [])
+    assert torch.equal(seq_t[-1], last_t) and torch.equal(seq_v[-1], last_v) and torch.equal(pooled_t, pt2)
+    taps = {}
+    R.forward_from_batch(sd, rcfg, batch, train=False, taps=taps)
+    for k, n in enumerate(ids):
+        for got, key in ((seq_t[k], "t%d" % n), (seq_v[k], "v%d" % n)):
+            ref = taps[key]
+            assert got.shape == ref.shape and got.dtype == torch.float32
+            assert rel_err(got.cpu(), ref.detach()) < 2e-2, (name, key)
+    with pytest.raises(NotImplementedError):
+        model.bert(*args, output_all_attention_masks=True)

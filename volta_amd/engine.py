@@ -459,6 +459,7 @@ class StepEngine:
         # first waits for the event of sub-layer k + 2, the previous user of that buffer set.
         self.n_sub = len(list(sublayer_schedule(cfg)))
         self.fwd_sub_start = []       # forward op index at which sub-layer k begins (the optimizer overlap cuts the list there)
+        self.sublayer_ids = [n for n, _ in sched]       # taps "t<n>" / "v<n>": both streams' states after sub-layer n, forward order
         for k, (n, typ) in enumerate(sched):
             self.sub_k = k
             self.fwd_sub_start.append(len(self.fwd.ops))

@@ -188,9 +188,10 @@ class BertModel(PreTrainedModel):
         root = self.__dict__.get("_root")
         if root is None:
             raise NotImplementedError("BertModel runs as part of BertForVLPreTraining (the HIP plan includes the heads)")
-        if output_all_encoded_layers or output_all_attention_masks:
-            raise NotImplementedError("intermediate layer / attention-map outputs are not materialised by the fused engine")
-        return root.encode(input_txt, input_imgs, image_loc, token_type_ids, attention_mask, image_attention_mask)
+        if output_all_attention_masks:
+            raise NotImplementedError("attention maps are not materialised by the fused attention kernel")
+        return root.encode(input_txt, input_imgs, image_loc, token_type_ids, attention_mask, image_attention_mask,
+                           output_all_encoded_layers=output_all_encoded_layers)
 
 
 class BertPreTrainingHeads(M.Holder):
@@ -504,8 +505,10 @@ class BertForVLPreTraining(PreTrainedModel):
                 itm = sc[:, :2]
             return scores_t, scores_v, itm, ([], []), pooled
 
-    def encode(self, input_ids, image_feat, image_loc, token_type_ids=None, attention_mask=None, image_attention_mask=None):
-        """BertModel.forward: (seq_t [B,T,H], seq_v [B,Rv,H], pooled_t, pooled_v, attention maps = ([], []))."""
+    def encode(self, input_ids, image_feat, image_loc, token_type_ids=None, attention_mask=None, image_attention_mask=None,
+               output_all_encoded_layers=False):
+        """BertModel.forward: (seq_t [B,T,H], seq_v [B,Rv,H], pooled_t, pooled_v, attention maps = ([], [])); with
+        `output_all_encoded_layers` the two sequences are lists with both streams' states after EVERY sub-layer (encoders.py:868-881)."""
         B, T = input_ids.shape
         R = image_feat.shape[1] - self.add_global_imgfeat
         dev = next(self.parameters()).device
@@ -520,8 +523,13 @@ class BertForVLPreTraining(PreTrainedModel):
         eng = self._last[0]
         H = self.config.hidden_size
         pt, pv = eng.taps["pooled_t"], eng.taps["pooled_v"]          # None where the fusion method has no such pooler
-        return (eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, self.config.v_hidden_size).float(),
-                None if pt is None else pt.float(), None if pv is None else pv.float(), ([], []))
+        Hv = self.config.v_hidden_size
+        if output_all_encoded_layers:
+            seq_t = [eng.taps["t%d" % n].view(B, T, H).float() for n in eng.sublayer_ids]
+            seq_v = [eng.taps["v%d" % n].view(B, Rv, Hv).float() for n in eng.sublayer_ids]
+        else:
+            seq_t, seq_v = eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, Hv).float()
+        return seq_t, seq_v, None if pt is None else pt.float(), None if pv is None else pv.float(), ([], [])
 
 
 # ======================================================================================== downstream tasks
@@ -627,7 +635,8 @@ class BertForVLTasks(PreTrainedModel):
         for n, p in self.named_parameters():
             p._vk_owner = self
 
-    def encode(self, input_ids, image_feat, image_loc, token_type_ids=None, attention_mask=None, image_attention_mask=None):
+    def encode(self, input_ids, image_feat, image_loc, token_type_ids=None, attention_mask=None, image_attention_mask=None,
+               output_all_encoded_layers=False):
         """BertModel.forward under no_grad (BertModel.forward delegates here)."""
         tensors, B, T, Rv = self._prep_inputs(input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask,
                                               None, None, None, None)
@@ -636,13 +645,18 @@ class BertForVLTasks(PreTrainedModel):
         eng = self._last[0]
         H = self.config.hidden_size
         pt, pv = eng.taps["pooled_t"], eng.taps["pooled_v"]          # None where the fusion method has no such pooler
-        return (eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, self.config.v_hidden_size).float(),
-                None if pt is None else pt.float(), None if pv is None else pv.float(), ([], []))
+        Hv = self.config.v_hidden_size
+        if output_all_encoded_layers:
+            seq_t = [eng.taps["t%d" % n].view(B, T, H).float() for n in eng.sublayer_ids]
+            seq_v = [eng.taps["v%d" % n].view(B, Rv, Hv).float() for n in eng.sublayer_ids]
+        else:
+            seq_t, seq_v = eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, Hv).float()
+        return seq_t, seq_v, None if pt is None else pt.float(), None if pv is None else pv.float(), ([], [])
 
     def forward(self, input_txt, input_imgs, image_loc, task_id, token_type_ids=None, attention_mask=None,
                 image_attention_mask=None, output_all_encoded_layers=False, output_all_attention_masks=False):
-        if output_all_encoded_layers or output_all_attention_masks:
-            raise NotImplementedError("intermediate layer / attention-map outputs are not materialised by the fused engine")
+        if output_all_attention_masks:
+            raise NotImplementedError("attention maps are not materialised by the fused attention kernel")
         if task_id not in self.task_cfg or task_id not in self.clfs_dict:
             raise KeyError("unknown task id %r" % (task_id,))
         tensors, B, T, Rv = self._prep_inputs(input_txt, input_imgs, image_loc, token_type_ids, attention_mask, image_attention_mask,
