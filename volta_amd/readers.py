@@ -9,6 +9,7 @@ into pinned staging buffers, one host-to-device copy per batch.
   ConceptCapLoaderTrain    volta/datasets/concept_cap_dataset.py:139-400: records -> the tensors the pre-training step takes
 
 No `lmdb`, `tensorpack`, `msgpack_numpy` or `zmq` is needed."""
+import contextlib
 import ctypes as C
 import json
 import os
@@ -185,18 +186,18 @@ class ConceptCapRecordReader:
     of the 13-field datapoint, plus a `__keys__` record that is skipped).  Every field is decoded by `vk_concap_record_decode` into its slot
     of pinned staging arrays shaped for `ConceptCapBatchProducer`: feat [B, R, F], cls [B, R, C], boxes [B, R, 4] (pixels), num_boxes [B],
     img_wh [B, 2], and -- `with_labels` -- obj / attr labels and confidences [B, R], attr scores [B, R, A].  A batch is decoded by ONE native call on
-    `threads` host threads (`vk_concap_records_decode`).  Two staging sets alternate so
+    `threads` host threads (`vk_concap_records_decode`).  `staging_sets` staging sets rotate so
     the copy of batch i can overlap the decode of batch i + 1.  The last batch may be smaller unless `drop_last`."""
 
     def __init__(self, path, batch_size, region_len=36, feature_size=2048, num_classes=1601, num_attrs=401, with_labels=False,
-                 drop_last=False, pin_memory=None, threads=None):
+                 drop_last=False, pin_memory=None, threads=None, staging_sets=2):
         self.db = LMDBReader(path)
         self.B, self.R, self.F, self.Cn, self.A = int(batch_size), int(region_len), int(feature_size), int(num_classes), int(num_attrs)
         self.with_labels, self.drop_last = with_labels, drop_last
         self.threads = int(threads) if threads else max(1, min(8, len(os.sched_getaffinity(0)) // 2))
         self.num_records = len(self.db) - (1 if self.db.get(b"__keys__") is not None else 0)
         pin = torch.cuda.is_available() if pin_memory is None else pin_memory
-        self._sets = [self._staging(pin) for _ in range(2)]
+        self._sets = [self._staging(pin) for _ in range(max(2, int(staging_sets)))]
 
     def _staging(self, pin):
         B, R = self.B, self.R
@@ -240,7 +241,7 @@ class ConceptCapRecordReader:
                 s = self._sets[which]
                 ids, caps = self._decode_batch(addrs, lens, s)
                 yield dict(s, image_id=ids, caption=caps)
-                which, addrs, lens = which ^ 1, [], []
+                which, addrs, lens = (which + 1) % len(self._sets), [], []
         if addrs and not self.drop_last:
             s = self._sets[which]
             ids, caps = self._decode_batch(addrs, lens, s)
@@ -270,14 +271,15 @@ class ConceptCapLoaderTrain:
 
     def __init__(self, annotations_path, features_path, tokenizer, bert_model=None, seq_len=36, batch_size=512, num_workers=0, cache=0,
                  local_rank=-1, objective=0, num_locs=5, add_global_imgfeat=None, region_len=36, vocab_size=None, seed=0, device="cuda",
-                 rank=None):
+                 rank=None, prefetch=2):
         import torch.distributed as dist
         from .data import ConceptCapBatchProducer
         if rank is None and local_rank != -1 and dist.is_available() and dist.is_initialized():
             rank = dist.get_rank()
         name = "training_feat_part_%d.lmdb" % rank if rank is not None else "training_feat_all.lmdb"
+        self.prefetch = max(0, int(prefetch))       # batches decoded ahead by a background thread (the native decode releases the GIL)
         self.records = ConceptCapRecordReader(os.path.join(features_path, name), batch_size, region_len=region_len, with_labels=True,
-                                              threads=num_workers or None)
+                                              threads=num_workers or None, staging_sets=self.prefetch + 2)
         self.num_dataset = self.records.num_records
         with open(os.path.join(annotations_path, "caption_train.json")) as f:
             corpus = list(json.load(f).values())
@@ -295,11 +297,28 @@ class ConceptCapLoaderTrain:
         self.add_global_imgfeat, self.objective, self.seed, self.device = add_global_imgfeat, objective, int(seed), device
         self.window = max(1, int(cache) // max(1, batch_size))
         self.epoch = 0
+        self._stream = None
 
     def __len__(self):
         return self.num_dataset
 
     def _produce(self, raw, step):
+        """One batch: copies and the producer's kernels run on the loader's own stream, so they overlap the training step that is still running
+        on the caller's stream; the host waits for THAT stream only (the pinned staging set is rewritten a few batches later), and the batch's
+        tensors are handed to the caller's stream (`record_stream`: the allocator must not recycle them under the model's kernels)."""
+        on_gpu = torch.cuda.is_available() and str(self.device).startswith("cuda")
+        if on_gpu and self._stream is None:
+            self._stream = torch.cuda.Stream()
+        with (torch.cuda.stream(self._stream) if on_gpu else contextlib.nullcontext()):
+            batch = self._produce_on_current_stream(raw, step)
+        if on_gpu:
+            self._stream.synchronize()
+            user = torch.cuda.current_stream()
+            for t in batch:
+                t.record_stream(user)
+        return batch + (raw["image_id"],)
+
+    def _produce_on_current_stream(self, raw, step):
         dev, B = self.device, len(raw["image_id"])
         toks = [self.encode(c)[:self.producer.cap_tokens.shape[1]] for c in raw["caption"]]
         own = torch.zeros(B, self.producer.cap_tokens.shape[1], dtype=torch.int32)
@@ -313,24 +332,63 @@ class ConceptCapLoaderTrain:
         out = self.producer(up["feat"], up["cls"], up["boxes"], up["num_boxes"], up["img_wh"], cap_index, self.seed * 1000003 + step)
         if self.num_locs == 4:
             out["image_loc"] = out["image_loc"][..., :4].contiguous()
-        batch = (out["input_ids"], out["input_mask"], out["segment_ids"], out["lm_label_ids"], out["is_match"], out["image_feat"], out["image_loc"],
-                 out["image_cls"], up["obj_labels"], up["obj_confs"], up["attr_labels"], up["attr_confs"], up["attr_scores"], out["image_label"],
-                 out["image_mask"])
-        if torch.cuda.is_available():
-            torch.cuda.current_stream().synchronize()        # the pinned staging set is refilled two batches later: the copies must have left it
-        return batch + (raw["image_id"],)
+        return (out["input_ids"], out["input_mask"], out["segment_ids"], out["lm_label_ids"], out["is_match"], out["image_feat"], out["image_loc"],
+                out["image_cls"], up["obj_labels"], up["obj_confs"], up["attr_labels"], up["attr_confs"], up["attr_scores"], out["image_label"],
+                out["image_mask"])
+
+    def _raw_batches(self):
+        """The record reader's batches, decoded up to `prefetch` batches ahead on a background thread.  A staging set is rewritten
+        `prefetch + 2` batches after it was handed out: one batch is with the consumer, one is being decoded, `prefetch` wait in the queue."""
+        if not self.prefetch:
+            yield from self.records
+            return
+        import queue
+        import threading
+        q, stop = queue.Queue(maxsize=self.prefetch), threading.Event()
+
+        def put(x):
+            while not stop.is_set():
+                try:
+                    q.put(x, timeout=0.1)
+                    return True
+                except queue.Full:
+                    pass
+            return False
+
+        def fill():
+            try:
+                for raw in self.records:
+                    if not put(raw):
+                        return
+                put(None)
+            except BaseException as e:          # handed to the consumer, raised there
+                put(e)
+
+        th = threading.Thread(target=fill, daemon=True)
+        th.start()
+        try:
+            while True:
+                raw = q.get()
+                if raw is None:
+                    return
+                if isinstance(raw, BaseException):
+                    raise raw
+                yield raw
+        finally:
+            stop.set()
+            th.join()
 
     def __iter__(self):
         g = torch.Generator().manual_seed(self.seed + 7919 * self.epoch)
         self.epoch += 1
         step = 0
         if self.window <= 1:
-            for raw in self.records:
+            for raw in self._raw_batches():
                 yield self._produce(raw, step)
                 step += 1
             return
         pool = []
-        for raw in self.records:
+        for raw in self._raw_batches():
             pool.append({k: (v.clone() if torch.is_tensor(v) else v) for k, v in raw.items()})
             if len(pool) == self.window:
                 yield self._produce(pool.pop(int(torch.randint(len(pool), (1,), generator=g))), step)
