@@ -513,6 +513,7 @@ typedef struct vk_concap_args {
     int32_t B, T, R, F, C, n_caps, cap_ld, vocab_size, cls_id, sep_id, mask_id;
     int32_t add_global;          /* 0 none, 1 first, 2 last                                             */
     int32_t objective;           /* 0, 1 (mismatched pairs lose their MLM / region labels), 2 (no swaps) */
+    int32_t visualization;       /* != 0: no caption swap, no token / region masking (BertPreprocessBatch(visualization=True), :514,622,652) */
 } vk_concap_args;
 int vk_concap_batch(const vk_concap_args* a, vk_stream_t s);
 

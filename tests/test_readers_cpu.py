@@ -254,3 +254,11 @@ def test_loader_file_rule_and_host_side_batching(tmp_path):
     assert ld.producer.cap_tokens.shape == (4 + 2, 12) and ld.producer.cap_len.tolist()[:4] == [len(dp[12].split()) for dp in dps] + [3]
     with pytest.raises(Exception):
         R.ConceptCapLoaderTrain(str(tmp_path), str(tmp_path), Tok(), seq_len=12, batch_size=2, region_len=6, device="cpu")   # no training_feat_all.lmdb
+    # the validation loader: its own file names, global feature first for any truthy flag, the visualization switch reaches the producer
+    write_lmdb(str(tmp_path / "validation_feat_all.lmdb"), {b"%08d" % i: pack_datapoint(dp) for i, dp in enumerate(dps[:2])})
+    (tmp_path / "caption_valid.json").write_text(json.dumps({dp[11]: dp[12] for dp in dps[:2]}))
+    val = R.ConceptCapLoaderVal(str(tmp_path), str(tmp_path), Tok(), seq_len=12, batch_size=2, region_len=6, add_global_imgfeat="last", visualization=True,
+                                device="cpu")
+    assert len(val) == 2 and val.add_global_imgfeat == "first" and val.producer.add_global == 1 and val.producer.visualization == 1 and val.window == 1
+    assert R.ConceptCapLoaderVal(str(tmp_path), str(tmp_path), Tok(), seq_len=12, batch_size=2, region_len=6, add_global_imgfeat=None,
+                                 device="cpu").producer.visualization == 0

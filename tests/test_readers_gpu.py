@@ -98,3 +98,30 @@ def test_model_trains_on_loader_batches(tmp_path):
     assert float(lm) > 5.0 and 0.3 < float(nsp) < 1.5
     g = model.bert.embeddings.word_embeddings.weight.grad
     assert g is not None and torch.isfinite(g).all() and float(g.abs().sum()) > 0
+
+
+def test_validation_loader_visualization_mode_masks_nothing(tmp_path):
+    """ConceptCapLoaderVal(visualization=True): every pair keeps its caption, no token and no region is masked, features arrive unchanged
+    behind the global row (concept_cap_dataset.py:514,622,652); without the flag the usual 15 % policy applies to the same records."""
+    from volta_amd import readers as R
+    Rl, B, T = 36, 4, 16
+    dps = _store(tmp_path, 8, Rl)
+    os.rename(str(tmp_path / "training_feat_all.lmdb"), str(tmp_path / "validation_feat_all.lmdb"))
+    os.rename(str(tmp_path / "caption_train.json"), str(tmp_path / "caption_valid.json"))
+    tok = Tok()
+    seen = 0
+    for batch in R.ConceptCapLoaderVal(str(tmp_path), str(tmp_path), tok, seq_len=T, batch_size=B, region_len=Rl, visualization=True, seed=3):
+        nb = len(batch[15])
+        mine = dps[seen:seen + nb]
+        assert int(batch[4].sum()) == 0 and int((batch[3] != -1).sum()) == 0 and int((batch[13] != -1).sum()) == 0
+        for b, dp in enumerate(mine):
+            ids = tok.encode(dp[12])[:T - 2]
+            assert batch[0][b, :len(ids) + 2].tolist() == [101] + ids + [102]
+            assert torch.equal(batch[5][b, 1:].cpu(), torch.tensor(dp[0]))
+            assert torch.allclose(batch[5][b, 0].cpu(), torch.tensor(dp[0]).sum(0) / Rl, rtol=1e-5, atol=1e-6)
+        seen += nb
+    assert seen == 8
+    masked = 0
+    for batch in R.ConceptCapLoaderVal(str(tmp_path), str(tmp_path), tok, seq_len=T, batch_size=B, region_len=Rl, seed=3):
+        masked += int((batch[3] != -1).sum()) + int((batch[13] == 1).sum())
+    assert masked > 0

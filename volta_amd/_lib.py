@@ -77,7 +77,7 @@ class ConcapArgs(C.Structure):
     _fields_ = [(n, c_p) for n in ("cap_tokens", "cap_len", "cap_index", "feat", "cls", "boxes", "num_boxes", "img_wh", "input_ids", "input_mask",
                                    "segment_ids", "lm_label_ids", "is_match", "image_feat", "image_loc", "image_cls", "image_label", "image_mask")] + \
                [("seed", C.c_uint64)] + [(n, i32) for n in ("B", "T", "R", "F", "C", "n_caps", "cap_ld", "vocab_size", "cls_id", "sep_id", "mask_id",
-                                                            "add_global", "objective")]
+                                                            "add_global", "objective", "visualization")]
 
 
 class ConcapRecord(C.Structure):

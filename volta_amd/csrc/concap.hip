@@ -21,7 +21,7 @@ __device__ __forceinline__ uint32_t cc_word(uint64_t seed, uint32_t stream, uint
 __device__ __forceinline__ double cc_sub(uint32_t w) { return ((double)w / 4294967296.0) / 0.15; }
 __device__ __forceinline__ bool cc_swap(const vk_concap_args& a, int b, int& cap) {
     cap = a.cap_index[b];
-    if (a.objective != 2 && (double)cc_word(a.seed, 3, b, 0) / 4294967296.0 > 0.5) {
+    if (a.objective != 2 && !a.visualization && (double)cc_word(a.seed, 3, b, 0) / 4294967296.0 > 0.5) {
         cap = (int)(cc_word(a.seed, 3, b, 1) % (uint32_t)a.n_caps);
         return true;
     }
@@ -39,7 +39,7 @@ __device__ __forceinline__ float cc_regions(const vk_concap_args& a, int b, int 
     const int R = a.R;
     for (int r = threadIdx.x; r < R; r += blockDim.x) {
         const uint32_t w = r < n ? cc_word(a.seed, 2, b, r) : 0xFFFFFFFFu;
-        const bool s = r < n && w < CC_T15;
+        const bool s = r < n && w < CC_T15 && !a.visualization;
         sel[r] = s;
         zero[r] = s && cc_sub(w) < 0.9;
     }
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(128) void concap_meta_kernel(const vk_concap_args a
             const int tok = a.cap_tokens[(size_t)cap * a.cap_ld + (t - 1)];
             const uint32_t w = cc_word(a.seed, 0, b, t - 1);
             id = tok; m = 1;
-            if (w < CC_T15) {
+            if (w < CC_T15 && !a.visualization) {
                 const double p = cc_sub(w);
                 if (p < 0.8) id = a.mask_id;
                 else if (p < 0.9) id = (int64_t)(cc_word(a.seed, 1, b, t - 1) % (uint32_t)a.vocab_size);

@@ -63,7 +63,7 @@ class ConceptCapBatchProducer:
     (pixels), `num_boxes [B]`, `img_wh [B, 2]`, `cap_index [B]`.  One call = three HIP launches (csrc/concap.hip)."""
 
     def __init__(self, captions, seq_len, region_len, vocab_size, add_global_imgfeat="first", objective=1, cls_id=101, sep_id=102, mask_id=103,
-                 device="cuda", extra_rows=0, min_ld=0, n_random=None):
+                 device="cuda", extra_rows=0, min_ld=0, n_random=None, visualization=False):
         """`extra_rows` empty rows behind the corpus (a loader writes each batch's own captions there and points `cap_index` at them);
         `n_random`: replacement captions are drawn from rows [0, n_random) (default: all of `captions`)."""
         from . import _lib as L
@@ -78,6 +78,7 @@ class ConceptCapBatchProducer:
         self.cap_tokens = tok.to(device)
         self.cap_len = torch.tensor([len(c) for c in captions] + [0] * int(extra_rows), dtype=torch.int32, device=device)
         self.n_random = len(captions) if n_random is None else int(n_random)
+        self.visualization = int(bool(visualization))        # no swap, no masking (the reference's validation loader can ask for it)
         self.device = device
 
     def __call__(self, feat, cls, boxes, num_boxes, img_wh, cap_index, seed):
@@ -99,7 +100,7 @@ class ConceptCapBatchProducer:
                          L.ptr(keep[4]), *[L.ptr(out[k]) for k in ("input_ids", "input_mask", "segment_ids", "lm_label_ids", "is_match", "image_feat",
                                                                     "image_loc", "image_cls", "image_label", "image_mask")],
                          C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF), B, self.T, R, F, Cn, self.n_random, self.cap_tokens.shape[1], self.V,
-                         self.ids[0], self.ids[1], self.ids[2], self.add_global, self.objective)
+                         self.ids[0], self.ids[1], self.ids[2], self.add_global, self.objective, self.visualization)
         L.check(L.lib.vk_concap_batch(C.byref(a), L.stream_ptr()))
         out["_keep"] = keep          # inputs stay alive until the stream has consumed them
         return out

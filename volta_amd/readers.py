@@ -6,7 +6,8 @@ into pinned staging buffers, one host-to-device copy per batch.
   ImageFeaturesH5Reader    volta/datasets/_image_features_reader.py:16-196 (same constructor, `len`, `reader[image_id]`)
   read_extraction_tsv      the rows data/conceptual_captions/preprocess_cc_train.py:57-72 yields
   ConceptCapRecordReader   tensorpack's `LMDBSerializer.load(lmdb_file, shuffle=False)` + batching: raw datapoints -> staging arrays
-  ConceptCapLoaderTrain    volta/datasets/concept_cap_dataset.py:139-400: records -> the tensors the pre-training step takes
+  ConceptCapLoaderTrain    volta/datasets/concept_cap_dataset.py:139-288: records -> the tensors the pre-training step takes
+  ConceptCapLoaderVal      volta/datasets/concept_cap_dataset.py:291-400
 
 No `lmdb`, `tensorpack`, `msgpack_numpy` or `zmq` is needed."""
 import contextlib
@@ -269,6 +270,12 @@ class ConceptCapLoaderTrain:
     come from Philox streams of (`seed`, batch index) instead of Python's `random` -- same distribution, different draws.  tensorpack's
     `LocallyShuffleData(ds, cache)` becomes a shuffle of whole batches inside a window of `cache // batch_size` batches."""
 
+    _caption_file, _visualization = "caption_train.json", False
+
+    @staticmethod
+    def _lmdb_name(rank):
+        return "training_feat_part_%d.lmdb" % rank if rank is not None else "training_feat_all.lmdb"
+
     def __init__(self, annotations_path, features_path, tokenizer, bert_model=None, seq_len=36, batch_size=512, num_workers=0, cache=0,
                  local_rank=-1, objective=0, num_locs=5, add_global_imgfeat=None, region_len=36, vocab_size=None, seed=0, device="cuda",
                  rank=None, prefetch=2):
@@ -276,12 +283,12 @@ class ConceptCapLoaderTrain:
         from .data import ConceptCapBatchProducer
         if rank is None and local_rank != -1 and dist.is_available() and dist.is_initialized():
             rank = dist.get_rank()
-        name = "training_feat_part_%d.lmdb" % rank if rank is not None else "training_feat_all.lmdb"
+        name = self._lmdb_name(rank)
         self.prefetch = max(0, int(prefetch))       # batches decoded ahead by a background thread (the native decode releases the GIL)
         self.records = ConceptCapRecordReader(os.path.join(features_path, name), batch_size, region_len=region_len, with_labels=True,
                                               threads=num_workers or None, staging_sets=self.prefetch + 2)
         self.num_dataset = self.records.num_records
-        with open(os.path.join(annotations_path, "caption_train.json")) as f:
+        with open(os.path.join(annotations_path, self._caption_file)) as f:
             corpus = list(json.load(f).values())
         self.encode = _encoder(tokenizer)
         self.n_corpus = len(corpus)
@@ -293,7 +300,8 @@ class ConceptCapLoaderTrain:
         self.seq_len, self.batch_size, self.num_locs = seq_len, batch_size, num_locs
         self.producer = ConceptCapBatchProducer([self.encode(c) for c in corpus], seq_len, region_len, vocab, add_global_imgfeat=add_global_imgfeat,
                                                 objective=objective, cls_id=ids["cls"], sep_id=ids["sep"], mask_id=ids["mask"], device=device,
-                                                extra_rows=batch_size, min_ld=seq_len, n_random=max(1, min(self.num_dataset, self.n_corpus)))
+                                                extra_rows=batch_size, min_ld=seq_len, n_random=max(1, min(self.num_dataset, self.n_corpus)),
+                                                visualization=self._visualization)
         self.add_global_imgfeat, self.objective, self.seed, self.device = add_global_imgfeat, objective, int(seed), device
         self.window = max(1, int(cache) // max(1, batch_size))
         self.epoch = 0
@@ -396,3 +404,21 @@ class ConceptCapLoaderTrain:
         while pool:
             yield self._produce(pool.pop(int(torch.randint(len(pool), (1,), generator=g))), step)
             step += 1
+
+
+class ConceptCapLoaderVal(ConceptCapLoaderTrain):
+    """Counterpart of the reference's ConceptCapLoaderVal (volta/datasets/concept_cap_dataset.py:291-400): `validation_feat_all.lmdb` and
+    `caption_valid.json`, records in file order (no shuffle window, no per-rank shards), and -- `visualization=True` -- neither caption swaps nor
+    token / region masking (:514,622,652).  As in the reference (:359) ANY truthy `add_global_imgfeat` puts the global feature FIRST, whatever the
+    config says about "last"."""
+    _caption_file = "caption_valid.json"
+
+    @staticmethod
+    def _lmdb_name(rank):
+        return "validation_feat_all.lmdb"
+
+    def __init__(self, annotations_path, features_path, tokenizer, bert_model=None, seq_len=36, batch_size=512, num_workers=0, cache=5000, objective=0,
+                 num_locs=5, add_global_imgfeat=True, visualization=False, **kw):
+        self._visualization = bool(visualization)
+        super().__init__(annotations_path, features_path, tokenizer, bert_model, seq_len=seq_len, batch_size=batch_size, num_workers=num_workers, cache=0,
+                         objective=objective, num_locs=num_locs, add_global_imgfeat="first" if add_global_imgfeat else None, **kw)
