@@ -266,7 +266,7 @@ class ConceptCapLoaderTrain:
 
     Pipeline: `ConceptCapRecordReader` (host, native decode into pinned memory) -> one asynchronous copy per array -> `ConceptCapBatchProducer`
     (`vk_concap_batch`: caption swap, token / region masking with IoU co-masking, box normalisation, global feature, on the device).
-    `tokenizer.encode(caption)` is the only per-record Python left; the corpus of `caption_train.json` is tokenised once.  Sampling decisions
+    `tokenizer.encode(caption)` is the only per-record Python left (it runs on the prefetch thread); the corpus of `caption_train.json` is tokenised once.  Sampling decisions
     come from Philox streams of (`seed`, batch index) instead of Python's `random` -- same distribution, different draws.  tensorpack's
     `LocallyShuffleData(ds, cache)` becomes a shuffle of whole batches inside a window of `cache // batch_size` batches."""
 
@@ -328,7 +328,8 @@ class ConceptCapLoaderTrain:
 
     def _produce_on_current_stream(self, raw, step):
         dev, B = self.device, len(raw["image_id"])
-        toks = [self.encode(c)[:self.producer.cap_tokens.shape[1]] for c in raw["caption"]]
+        ld = self.producer.cap_tokens.shape[1]
+        toks = [t[:ld] for t in (raw["tokens"] if "tokens" in raw else [self.encode(c) for c in raw["caption"]])]
         own = torch.zeros(B, self.producer.cap_tokens.shape[1], dtype=torch.int32)
         for i, t in enumerate(toks):
             own[i, :len(t)] = torch.tensor(t, dtype=torch.int32)
@@ -366,6 +367,7 @@ class ConceptCapLoaderTrain:
         def fill():
             try:
                 for raw in self.records:
+                    raw["tokens"] = [self.encode(c) for c in raw["caption"]]      # tokenised here, off the thread that issues the training step
                     if not put(raw):
                         return
                 put(None)
