@@ -262,3 +262,43 @@ def test_loader_file_rule_and_host_side_batching(tmp_path):
     assert len(val) == 2 and val.add_global_imgfeat == "first" and val.producer.add_global == 1 and val.producer.visualization == 1 and val.window == 1
     assert R.ConceptCapLoaderVal(str(tmp_path), str(tmp_path), Tok(), seq_len=12, batch_size=2, region_len=6, add_global_imgfeat=None,
                                  device="cpu").producer.visualization == 0
+
+
+def test_damaged_stores_raise_instead_of_crashing(tmp_path):
+    """Byte flips in page headers / offset tables / nodes and truncated files: every call either works or raises VoltaHipError -- the walker
+    never leaves the mapping (tools/fuzz/run.sh drives the same mutations under AddressSanitizer; an entry count read from a damaged
+    header once sent it 60 KB past the page)."""
+    import random
+    R = _readers()
+    from volta_amd._lib import VoltaHipError
+    recs = _records(60)
+    good = str(tmp_path / "good.lmdb")
+    write_lmdb(good, recs, max_keys=4)
+    orig = open(good, "rb").read()
+    rnd = random.Random(3)
+    outcomes = {"ok": 0, "error": 0}
+    for it in range(250):
+        buf = bytearray(orig)
+        for _ in range(rnd.randint(1, 6)):
+            pg = rnd.randrange(len(buf) // 4096)
+            buf[pg * 4096 + (rnd.randrange(64) if rnd.random() < 0.7 else rnd.randrange(4096))] = rnd.randrange(256)
+        if it % 10 == 0:
+            buf = buf[:4096 * rnd.randrange(2, len(buf) // 4096)]
+        bad = str(tmp_path / "bad.lmdb")
+        with open(bad, "wb") as f:
+            f.write(buf)
+        try:
+            db = R.LMDBReader(bad)
+            for n, (k, v) in enumerate(db):
+                bytes(v[-4:])
+                if n > 500:
+                    break
+            for k in list(recs)[:8]:
+                v = db.get(k)
+                if v is not None:
+                    bytes(v[-4:])
+            db.close()
+            outcomes["ok"] += 1
+        except VoltaHipError:
+            outcomes["error"] += 1
+    assert outcomes["ok"] > 0 and outcomes["error"] > 0

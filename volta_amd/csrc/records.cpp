@@ -92,12 +92,20 @@ Meta read_meta(const uint8_t* p, size_t avail) {
     return m;
 }
 
-inline int num_keys(const uint8_t* pg) { return ((int)rd<uint16_t>(pg + 12) - (int)PAGE_HDR) >> 1; }
+// entries of a branch / leaf page; 0 for a page whose `lower` bound is not a whole offset table inside the page (a damaged file must not
+// send the walker outside the mapping)
+inline int num_keys(const vk_lmdb* db, const uint8_t* pg) {
+    const uint32_t lower = rd<uint16_t>(pg + 12), upper = rd<uint16_t>(pg + 14);
+    if (lower < PAGE_HDR || (lower & 1) || lower > upper || upper > db->meta.psize) return 0;
+    return (int)((lower - PAGE_HDR) >> 1);
+}
 
 // node i of a page: lo (2) | hi (2) | flags (2) | ksize (2) | key | data
 inline const uint8_t* node_at(const vk_lmdb* db, const uint8_t* pg, int i) {
+    const int n = num_keys(db, pg);
+    if (i < 0 || i >= n) return nullptr;
     const uint16_t off = rd<uint16_t>(pg + PAGE_HDR + 2 * (size_t)i);
-    if (off < PAGE_HDR + 2 * (size_t)num_keys(pg) || (size_t)off + 8 > db->meta.psize) return nullptr;
+    if (off < PAGE_HDR + 2 * (size_t)n || (size_t)off + 8 > db->meta.psize) return nullptr;
     return pg + off;
 }
 
@@ -139,7 +147,7 @@ int descend_left(vk_lmdb* db) {
         if (!pg) return set_error("vk_lmdb: page %llu outside the file", (unsigned long long)db->pg[db->top]);
         const uint16_t fl = rd<uint16_t>(pg + 10);
         if (fl & P_LEAF) return (fl & P_LEAF2) ? set_error("vk_lmdb: DUPFIXED leaf pages are not supported") : 0;
-        if (!(fl & P_BRANCH) || num_keys(pg) < 1) return set_error("vk_lmdb: page %llu is neither branch nor leaf", (unsigned long long)db->pg[db->top]);
+        if (!(fl & P_BRANCH) || num_keys(db, pg) < 1) return set_error("vk_lmdb: page %llu is neither branch nor leaf", (unsigned long long)db->pg[db->top]);
         if (db->top + 1 >= MAX_DEPTH) return set_error("vk_lmdb: tree deeper than %d", MAX_DEPTH);
         const uint8_t* n = node_at(db, pg, db->idx[db->top]);
         if (!n) return set_error("vk_lmdb: bad node offset");
@@ -217,7 +225,7 @@ extern "C" int vk_lmdb_next(vk_lmdb* db, const void** key, size_t* klen, const v
     while (db->top >= 0) {
         const uint8_t* pg = db->page(db->pg[db->top]);
         if (!pg) return set_error("vk_lmdb_next: page outside the file");
-        if (db->idx[db->top] < num_keys(pg)) {
+        if (db->idx[db->top] < num_keys(db, pg)) {
             if (rd<uint16_t>(pg + 10) & P_LEAF) {
                 const uint8_t* n = node_at(db, pg, db->idx[db->top]);
                 if (!n) return set_error("vk_lmdb_next: bad node offset");
@@ -243,7 +251,7 @@ extern "C" int vk_lmdb_get(const vk_lmdb* db, const void* key, size_t klen, cons
         const uint8_t* pg = db->page(pgno);
         if (!pg) return set_error("vk_lmdb_get: page %llu outside the file", (unsigned long long)pgno);
         const uint16_t fl = rd<uint16_t>(pg + 10);
-        const int n = num_keys(pg);
+        const int n = num_keys(db, pg);
         if (fl & P_LEAF) {
             if (fl & P_LEAF2) return set_error("vk_lmdb_get: DUPFIXED leaf pages are not supported");
             int lo = 0, hi = n - 1;
