@@ -561,6 +561,19 @@ int vk_concap_record_decode(const void* rec, size_t len, vk_concap_record* r);
    *failed (optional) = its index. */
 int vk_concap_records_decode(const void* const* recs, const size_t* lens, vk_concap_record* slots, int n, int threads, int* failed);
 
+/* BERT tokenisation of captions (basic tokenizer + WordPiece), replacing `self.tokenizer.encode(caption)` of BertPreprocessBatch.__call__
+ * (concept_cap_dataset.py:465; tokenizer = pytorch-transformers 1.1 BertTokenizer, requirements.txt:39).  `vocab_path`: BERT's vocab.txt, one
+ * token per line, id = line number.  Ids come without [CLS] / [SEP]. */
+typedef struct vk_wordpiece vk_wordpiece;
+int vk_wordpiece_open(const char* vocab_path, int lowercase, vk_wordpiece** out);
+void vk_wordpiece_close(vk_wordpiece* t);
+int vk_wordpiece_vocab_size(const vk_wordpiece* t);
+int vk_wordpiece_token_id(const vk_wordpiece* t, const char* token);            /* -1 if absent */
+/* returns the number of ids of `text` (UTF-8, len bytes); the first min(that, cap) are written */
+int vk_wordpiece_encode(const vk_wordpiece* t, const char* text, size_t len, int32_t* ids, int cap);
+/* n texts -> ids [n, ld] (zero-padded, truncated at ld), counts[i] = min(#ids, ld), on `threads` host threads */
+int vk_wordpiece_encode_batch(const vk_wordpiece* t, const char* const* texts, const size_t* lens, int n, int32_t* ids, int ld, int32_t* counts, int threads);
+
 /* base64 text (standard or url-safe alphabet, padding optional, line breaks skipped) -> bytes: the `boxes` / `features` / `cls_prob`
  * columns of the extraction TSV (data/conceptual_captions/preprocess_cc_train.py:66-68) and of the task feature stores
  * (_image_features_reader.py:87-88). */

@@ -125,3 +125,29 @@ def test_validation_loader_visualization_mode_masks_nothing(tmp_path):
     for batch in R.ConceptCapLoaderVal(str(tmp_path), str(tmp_path), tok, seq_len=T, batch_size=B, region_len=Rl, seed=3):
         masked += int((batch[3] != -1).sum()) + int((batch[13] == 1).sum())
     assert masked > 0
+
+
+def test_loader_with_the_native_tokenizer(tmp_path):
+    """WordPieceTokenizer in the loader: the batch's captions are tokenised by one native call; the text rows are [CLS] ids [SEP] of each
+    record's own caption wherever the pair was not swapped and no token was masked."""
+    from volta_amd import readers as R
+    Rl, B, T = 36, 4, 16
+    dps = _store(tmp_path, 8, Rl)
+    vocab = ["[PAD]", "[UNK]", "[CLS]", "[SEP]", "[MASK]"] + ["w", "##%d" % 0] + ["##%d" % i for i in range(1, 10)] + [str(i) for i in range(10)]
+    (tmp_path / "vocab.txt").write_text("\n".join(vocab) + "\n")
+    tok = R.WordPieceTokenizer(str(tmp_path / "vocab.txt"))
+    assert tok.encode("w12") == [5, vocab.index("##1"), vocab.index("##2")]
+    ld = R.ConceptCapLoaderVal(str(_as_val(tmp_path)), str(tmp_path), tok, seq_len=T, batch_size=B, region_len=Rl, visualization=True, seed=3)
+    seen = 0
+    for batch in ld:
+        for b in range(len(batch[15])):
+            ids = tok.encode(dps[seen + b][12])[:T - 2]
+            assert batch[0][b, :len(ids) + 2].tolist() == [2] + ids + [3] and int(batch[1][b].sum()) == len(ids) + 2
+        seen += len(batch[15])
+    assert seen == 8
+
+
+def _as_val(tmp_path):
+    os.rename(str(tmp_path / "training_feat_all.lmdb"), str(tmp_path / "validation_feat_all.lmdb"))
+    os.rename(str(tmp_path / "caption_train.json"), str(tmp_path / "caption_valid.json"))
+    return tmp_path

@@ -62,5 +62,25 @@ int main(int argc, char** argv) {
         free(h); free(o);
     }
     printf("b64 done\n");
+    // tokenizer: random bytes (valid and broken UTF-8, long runs without spaces), exact-size heap copies
+    if (argc > 4) {
+        vk_wordpiece* t = nullptr;
+        if (vk_wordpiece_open(argv[4], 1, &t)) { printf("vocab: %s\n", vk_last_error()); return 1; }
+        long total = 0;
+        for (int it = 0; it < iters * 20; ++it) {
+            size_t n = rnd() % 300;
+            char* h = (char*)malloc(n ? n : 1);
+            const int mode = rnd() % 4;
+            for (size_t i = 0; i < n; ++i) h[i] = mode == 0 ? (char)(rnd() & 255) : mode == 1 ? "dog cat.,!  \t\xc3\xa9\xe4\xb8\xad\xf0\x9f\x98\x80" "ab"[rnd() % 24] : mode == 2 ? (char)('a' + rnd() % 3) : (char)(0x80 | (rnd() & 0x7f));
+            int cap = rnd() % 64;
+            int32_t* ids = (int32_t*)malloc(sizeof(int32_t) * (cap ? cap : 1));
+            int k = vk_wordpiece_encode(t, h, n, ids, cap);
+            if (k < 0) { printf("encode failed\n"); return 1; }
+            total += k;
+            free(ids); free(h);
+        }
+        vk_wordpiece_close(t);
+        printf("wordpiece: %ld ids\n", total);
+    }
     return 0;
 }

@@ -217,6 +217,12 @@ _sig("vk_lmdb_next", C.c_int, c_p, C.POINTER(c_p), C.POINTER(C.c_size_t), C.POIN
 _sig("vk_lmdb_get", C.c_int, c_p, C.c_char_p, C.c_size_t, C.POINTER(c_p), C.POINTER(C.c_size_t))
 _sig("vk_concap_record_decode", C.c_int, c_p, C.c_size_t, C.POINTER(ConcapRecord))
 _sig("vk_concap_records_decode", C.c_int, C.POINTER(c_p), C.POINTER(C.c_size_t), C.POINTER(ConcapRecord), C.c_int, C.c_int, C.POINTER(C.c_int))
+_sig("vk_wordpiece_open", C.c_int, C.c_char_p, C.c_int, C.POINTER(c_p))
+_sig("vk_wordpiece_close", None, c_p)
+_sig("vk_wordpiece_vocab_size", C.c_int, c_p)
+_sig("vk_wordpiece_token_id", C.c_int, c_p, C.c_char_p)
+_sig("vk_wordpiece_encode", C.c_int, c_p, C.c_char_p, C.c_size_t, c_p, C.c_int)
+_sig("vk_wordpiece_encode_batch", C.c_int, c_p, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_int, c_p, C.c_int, c_p, C.c_int)
 _sig("vk_b64_decode", C.c_int, C.c_char_p, C.c_size_t, c_p, C.c_size_t, C.POINTER(C.c_size_t))
 _sig("vk_vlbert_positions", C.c_int, c_p, C.c_int, C.c_int, C.c_int, c_p, c_p, c_p)
 _sig("vk_vis_loss_fwd", C.c_int, C.POINTER(VisLossArgs), c_p)
@@ -253,7 +259,8 @@ EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_c
            "vk_pool_fuse_fwd", "vk_pool_fuse_bwd", "vk_text_end_rows", "vk_vlbert_obj_ids", "vk_vlbert_positions", "vk_vis_loss_fwd", "vk_vis_loss_bwd", "vk_nce_negatives",
            "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_grad_norm_clip_masked", "vk_adamw_step",
            "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_side_tail", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_join_from", "vk_side_enable", "vk_concap_batch",
-           "vk_lmdb_open", "vk_lmdb_close", "vk_lmdb_entries", "vk_lmdb_first", "vk_lmdb_next", "vk_lmdb_get", "vk_concap_record_decode", "vk_concap_records_decode", "vk_b64_decode"]
+           "vk_lmdb_open", "vk_lmdb_close", "vk_lmdb_entries", "vk_lmdb_first", "vk_lmdb_next", "vk_lmdb_get", "vk_concap_record_decode", "vk_concap_records_decode", "vk_b64_decode",
+           "vk_wordpiece_open", "vk_wordpiece_close", "vk_wordpiece_vocab_size", "vk_wordpiece_token_id", "vk_wordpiece_encode", "vk_wordpiece_encode_batch"]
 
 
 def check(rc):

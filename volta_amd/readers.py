@@ -8,6 +8,7 @@ into pinned staging buffers, one host-to-device copy per batch.
   ConceptCapRecordReader   tensorpack's `LMDBSerializer.load(lmdb_file, shuffle=False)` + batching: raw datapoints -> staging arrays
   ConceptCapLoaderTrain    volta/datasets/concept_cap_dataset.py:139-288: records -> the tensors the pre-training step takes
   ConceptCapLoaderVal      volta/datasets/concept_cap_dataset.py:291-400
+  WordPieceTokenizer       the `tokenizer.encode(caption)` of :465 (pytorch-transformers' BertTokenizer) in native code
 
 No `lmdb`, `tensorpack`, `msgpack_numpy` or `zmq` is needed."""
 import contextlib
@@ -249,6 +250,61 @@ class ConceptCapRecordReader:
             yield dict({k: v[:len(ids)] for k, v in s.items()}, image_id=ids, caption=caps)
 
 
+class WordPieceTokenizer:
+    """BERT's tokenizer in native code (`csrc/wordpiece.cpp`: basic tokenizer + WordPiece over a `vocab.txt`), with the handful of attributes
+    the loaders read from a tokenizer.  `encode(text)` -> ids without [CLS] / [SEP] (what pytorch-transformers 1.1's `BertTokenizer.encode`
+    returned, concept_cap_dataset.py:465); `encode_batch(texts, ld)` -> (ids [n, ld] int32 zero-padded / truncated, counts [n]) in one call on
+    several host threads."""
+
+    def __init__(self, vocab_file, do_lower_case=True, threads=None):
+        h = C.c_void_p()
+        L.check(L.lib.vk_wordpiece_open(os.fsencode(vocab_file), int(bool(do_lower_case)), C.byref(h)))
+        self._h = h
+        self.vocab_file = vocab_file
+        self.vocab_size = int(L.lib.vk_wordpiece_vocab_size(h))
+        self.threads = int(threads) if threads else max(1, min(8, len(os.sched_getaffinity(0)) // 2))
+        for name in ("unk", "cls", "sep", "mask", "pad"):
+            setattr(self, name + "_token", "[%s]" % name.upper())
+            i = self.convert_tokens_to_ids("[%s]" % name.upper())
+            setattr(self, name + "_token_id", i)
+
+    def __len__(self):
+        return self.vocab_size
+
+    def convert_tokens_to_ids(self, token):
+        if isinstance(token, (list, tuple)):
+            return [self.convert_tokens_to_ids(t) for t in token]
+        i = int(L.lib.vk_wordpiece_token_id(self._h, token.encode("utf-8")))
+        return i if i >= 0 else self.unk_token_id
+
+    def encode(self, text, add_special_tokens=False):
+        raw = text.encode("utf-8", "replace")
+        cap = 2 * len(raw) + 8
+        buf = (C.c_int32 * cap)()
+        n = L.lib.vk_wordpiece_encode(self._h, raw, len(raw), buf, cap)
+        if n < 0:
+            L.check(n)
+        ids = list(buf[:n])
+        return [self.cls_token_id] + ids + [self.sep_token_id] if add_special_tokens else ids
+
+    def encode_batch(self, texts, ld):
+        n = len(texts)
+        raws = [t.encode("utf-8", "replace") for t in texts]
+        ids, counts = torch.zeros(n, ld, dtype=torch.int32), torch.zeros(n, dtype=torch.int32)
+        if n:
+            arr, lens = (C.c_char_p * n)(*raws), (C.c_size_t * n)(*[len(r) for r in raws])
+            L.check(L.lib.vk_wordpiece_encode_batch(self._h, arr, lens, n, C.c_void_p(ids.data_ptr()), ld, C.c_void_p(counts.data_ptr()), self.threads))
+        return ids, counts
+
+    def __del__(self):
+        try:
+            if self._h is not None:
+                L.lib.vk_wordpiece_close(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
 def _encoder(tokenizer):
     """caption -> token ids without [CLS] / [SEP] (what pytorch-transformers 1.1's `tokenizer.encode` returned, :465)."""
     def encode(text):
@@ -290,7 +346,7 @@ class ConceptCapLoaderTrain:
         self.num_dataset = self.records.num_records
         with open(os.path.join(annotations_path, self._caption_file)) as f:
             corpus = list(json.load(f).values())
-        self.encode = _encoder(tokenizer)
+        self.tokenizer, self.encode = tokenizer, _encoder(tokenizer)
         self.n_corpus = len(corpus)
         vocab = vocab_size if vocab_size is not None else getattr(tokenizer, "vocab_size", None) or len(tokenizer.vocab)
         ids = {n: getattr(tokenizer, n + "_token_id", None) for n in ("cls", "sep", "mask")}
@@ -328,13 +384,9 @@ class ConceptCapLoaderTrain:
 
     def _produce_on_current_stream(self, raw, step):
         dev, B = self.device, len(raw["image_id"])
-        ld = self.producer.cap_tokens.shape[1]
-        toks = [t[:ld] for t in (raw["tokens"] if "tokens" in raw else [self.encode(c) for c in raw["caption"]])]
-        own = torch.zeros(B, self.producer.cap_tokens.shape[1], dtype=torch.int32)
-        for i, t in enumerate(toks):
-            own[i, :len(t)] = torch.tensor(t, dtype=torch.int32)
+        own, lens = raw["tokens"] if "tokens" in raw else self._tokenise(raw["caption"])
         self.producer.cap_tokens[self.n_corpus:self.n_corpus + B].copy_(own, non_blocking=True)
-        self.producer.cap_len[self.n_corpus:self.n_corpus + B].copy_(torch.tensor([len(t) for t in toks], dtype=torch.int32), non_blocking=True)
+        self.producer.cap_len[self.n_corpus:self.n_corpus + B].copy_(lens, non_blocking=True)
         up = {k: raw[k].to(dev, non_blocking=True) for k in ("feat", "cls", "boxes", "num_boxes", "img_wh", "obj_labels", "obj_confs",
                                                              "attr_labels", "attr_confs", "attr_scores")}
         cap_index = torch.arange(self.n_corpus, self.n_corpus + B, dtype=torch.int32, device=dev)
@@ -344,6 +396,18 @@ class ConceptCapLoaderTrain:
         return (out["input_ids"], out["input_mask"], out["segment_ids"], out["lm_label_ids"], out["is_match"], out["image_feat"], out["image_loc"],
                 out["image_cls"], up["obj_labels"], up["obj_confs"], up["attr_labels"], up["attr_confs"], up["attr_scores"], out["image_label"],
                 out["image_mask"])
+
+    def _tokenise(self, captions):
+        """This batch's captions -> (ids [B, ld] int32, lengths [B] int32): one native call with a `WordPieceTokenizer`, `tokenizer.encode` per
+        caption otherwise."""
+        ld = self.producer.cap_tokens.shape[1]
+        if isinstance(self.tokenizer, WordPieceTokenizer):
+            return self.tokenizer.encode_batch(captions, ld)
+        toks = [self.encode(c)[:ld] for c in captions]
+        own = torch.zeros(len(toks), ld, dtype=torch.int32)
+        for i, t in enumerate(toks):
+            own[i, :len(t)] = torch.tensor(t, dtype=torch.int32)
+        return own, torch.tensor([len(t) for t in toks], dtype=torch.int32)
 
     def _raw_batches(self):
         """The record reader's batches, decoded up to `prefetch` batches ahead on a background thread.  A staging set is rewritten
@@ -367,7 +431,7 @@ class ConceptCapLoaderTrain:
         def fill():
             try:
                 for raw in self.records:
-                    raw["tokens"] = [self.encode(c) for c in raw["caption"]]      # tokenised here, off the thread that issues the training step
+                    raw["tokens"] = self._tokenise(raw["caption"])      # tokenised here, off the thread that issues the training step
                     if not put(raw):
                         return
                 put(None)
