@@ -36,7 +36,7 @@ def test_struct_layouts_match_the_header():
     pairs = {"vk_dropout": L.Dropout, "vk_gemm_problem": L.GemmProblem, "vk_drop_rows": L.DropRows, "vk_ln_args": L.LnArgs,
              "vk_ln_bwd_args": L.LnBwdArgs, "vk_attn_args": L.AttnArgs, "vk_attn_bwd_args": L.AttnBwdArgs, "vk_embed_args": L.EmbedArgs,
              "vk_embed_bwd_args": L.EmbedBwdArgs, "vk_xent_args": L.XentArgs, "vk_kl_args": L.KlArgs, "vk_vis_loss_args": L.VisLossArgs, "vk_adamw_args": L.AdamwArgs,
-             "vk_generic_args": L.GenericArgs, "vk_op": L.Op, "vk_concap_args": L.ConcapArgs, "vk_tail_job": L.TailJob, "vk_gemm_fp8_problem": L.GemmFp8Problem}
+             "vk_generic_args": L.GenericArgs, "vk_op": L.Op, "vk_concap_args": L.ConcapArgs, "vk_concap_record": L.ConcapRecord, "vk_tail_job": L.TailJob, "vk_gemm_fp8_problem": L.GemmFp8Problem}
     src = '#include <stdio.h>\n#include "volta_hip.h"\nint main(void){' + "".join(
         'printf("%s %%zu\\n", sizeof(%s));' % (n, n) for n in pairs) + "return 0;}"
     with tempfile.TemporaryDirectory() as d:
