@@ -12,13 +12,18 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port):
+def _worker(rank, world, port, shared_gpu=False):
+    """`shared_gpu`: every rank on cuda:0 with gloo collectives (RCCL refuses two ranks on one device) -- how tools/ddp_check.py runs the same
+    assertions on a one-GPU box."""
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-    torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    torch.cuda.set_device(0 if shared_gpu else rank)
+    if shared_gpu:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    else:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     from test_engine_gpu import build
     from oracle import volta_ref as R
     from volta_amd.parallel import DistributedDataParallel
