@@ -34,7 +34,7 @@ class LMDBReader:
         self.path = path
 
     def __len__(self):
-        return int(L.lib.vk_lmdb_entries(self._h))
+        return int(L.lib.vk_lmdb_entries(self._handle()))
 
     @staticmethod
     def _view(p, n):
