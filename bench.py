@@ -52,6 +52,7 @@ def gemm_flops(eng, plan):
     for i, (kind, layout, epi, nprob, arr, _, _) in enumerate(plan.ops):
         if kind not in (L.OP_GEMM, L.OP_GEMM_FP8):
             continue
+        layout &= 0xFF                     # the op carries a tile geometry above the layout
         fl, by = 0.0, 0.0
         for j in range(nprob):
             q = arr[j].p if kind == L.OP_GEMM_FP8 else arr[j]
@@ -263,6 +264,8 @@ def main():
     from volta_amd import _lib as L
     if a.serial:
         L.lib.vk_side_enable(0)
+    if os.environ.get("VK_SIDE_LOW_PRIORITY"):          # experiment switch (tools/): side streams at the device's lowest priority
+        L.lib.vk_side_set_low_priority(int(os.environ["VK_SIDE_LOW_PRIORITY"]))
 
     cfg = BertConfig.from_json_file(os.path.join(ROOT, "config", a.config + ".json"))
     torch.manual_seed(1234)
@@ -322,6 +325,10 @@ def main():
             if a.dtype == "fp8":
                 out["roofline"]["peak_note"] = ("dense fp8 MFMA peak; only the forward Q|K|V / FFN projections run on the e4m3 MFMA, attention output, "
                                                 "heads and the whole backward stay bf16 (peak 2500)")
+        if world > 1 and "roofline" in out:
+            out["roofline"]["note"] = ("N > 1: this is the whole-step figure per GPU (pairs/s / N x GFLOP/pair); the GEMM-family roofline with its live "
+                                       "launch timing, `traffic` (PMC) and `cpu_baseline` are measured at N = 1 only -- profiled extra steps would "
+                                       "desynchronise the ranks' collectives")
         if not a.no_kernel_timing and world == 1:      # extra profiled steps would desynchronise the ranks' collectives
             eng = model._last[0]
             eng.fwd.enable_timing(True)
@@ -352,7 +359,7 @@ def main():
                                 arr, nprob = op[4], op[3]
                                 pr = [(arr[j].p if op[0] == L.OP_GEMM_FP8 else arr[j]) for j in range(min(nprob, 4))]
                                 shapes = ("fp8 " if op[0] == L.OP_GEMM_FP8 else "") + ";".join("%dx%dx%d" % (q.M, q.N, q.K) for q in pr)
-                                fh.write("%s gemm layout=%d epi=%d nprob=%d [%s] %.1f us %.0f TF/s\n" % (key, op[1], op[2], nprob, shapes, tms[key] * 1e3, fl[key] / (tms[key] * 1e-3) / 1e12))
+                                fh.write("%s gemm layout=%d epi=%d nprob=%d [%s] %.1f us %.0f TF/s\n" % (key, op[1] & 0xFF, op[2], nprob, shapes, tms[key] * 1e3, fl[key] / (tms[key] * 1e-3) / 1e12))
                             else:
                                 fh.write("%s kind=%d %.1f us\n" % (key, op[0], tms[key] * 1e3))
             eng.fwd.enable_timing(False)

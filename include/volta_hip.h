@@ -74,16 +74,30 @@ typedef struct vk_gemm_problem {
     int32_t M, N, K;
     int32_t lda, ldb, ldc, ldr;
     int32_t n_store;       /* VK_EPI_F32: zero-fill columns up to here (>= N), else 0 */
+    /* Split accumulation (nparts >= 2; 0 / 1 = off): `nparts` problems of ONE launch with the same M, N, C, epilogue operands, `ws` and
+       `cnt` and part = 0 .. nparts-1 are K-slices (or row chunks, TN) of one product.  Every workgroup leaves its fp32 partial tile in
+       `ws`; the workgroup that arrives LAST at a tile (ticket on cnt[tile]) sums the partials in part order -- the result does not depend
+       on the arrival order -- and runs the epilogue.  No spinning: a launch completes under any residency.  Needs the 256-row tile
+       geometries (258 / 259 of vk_gemm_grouped_ex, one tile per workgroup) and no `dyn`.
+       ws:  vk_gemm_split_workspace_bytes(layout, M, N, nparts, geometry) bytes, 16-byte aligned, contents irrelevant;
+       cnt: one int32 per output tile (same query, second result), ZERO before the first launch; every launch leaves it zero. */
+    void* ws;
+    int32_t* cnt;
+    int32_t part, nparts;
 } vk_gemm_problem;
 #define VK_GEMM_MAX_GROUP 32
 /* One launch for up to VK_GEMM_MAX_GROUP independent problems of the same layout / epilogue. */
 int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, vk_stream_t s);
 /* Same with the tile geometry chosen by the caller instead of the shape heuristic (0 = heuristic): 128 (128 x 128 tiles, 4 waves),
  * 258 / 259 / 260 (256 x 256 / 192 / 128 tiles, 8 waves, LDS-DMA ring), optionally OR-ed with VK_GEMM_PERSISTENT (one workgroup per CU
- * walks the tile list; NT / NN without `dyn`) or VK_GEMM_ONE_TILE_PER_WG.  A per-call argument, no library state: re-entrant. */
+ * walks the tile list; NT / NN without `dyn`) or VK_GEMM_ONE_TILE_PER_WG; 261 (256 x 128 tiles, 4 waves, 72 KiB of LDS: two
+ * workgroups per CU, csrc/gemm4w.hip).  A per-call argument, no library state: re-entrant. */
 #define VK_GEMM_PERSISTENT 0x1000
 #define VK_GEMM_ONE_TILE_PER_WG 0x2000
 int vk_gemm_grouped_ex(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, int geometry, vk_stream_t s);
+/* Workspace of a split accumulation (see vk_gemm_problem::ws): bytes of `ws` for one product [M, N] cut into `nparts` parts under tile
+ * geometry 258 / 259; *tiles receives the number of int32 counters `cnt` needs.  Host-side arithmetic, no device work. */
+size_t vk_gemm_split_workspace_bytes(int layout, int M, int N, int nparts, int geometry, int* tiles);
 
 /* fp8 (OCP e4m3) forward projections on v_mfma_scale_f32_16x16x128_f8f6f4 (BASELINE.json configs[4]; the reference is fp32, the
  * sites are the nn.Linear forwards of volta/encoders.py:242-255, 495-499, 552-565).  Layout NT only: C[M,N] = (A8[M,K] . B8[N,K]^T)
@@ -381,6 +395,13 @@ int vk_grad_norm_workspace_floats(void);
 int vk_grad_norm_clip(const float* g, int64_t n, float pre_scale, float max_norm, float* partial, float* out, vk_stream_t s);
 /* same, leaving out the 1024-element chunks whose chunk_class is VK_CHUNK_SKIP (chunk_class NULL: all chunks) */
 int vk_grad_norm_clip_masked(const float* g, int64_t n, const uint8_t* chunk_class, float pre_scale, float max_norm, float* partial, float* out, vk_stream_t s);
+/* Shard-decomposable form of the same norm, for data-parallel ranks that each own a part of the gradient arena (volta_amd/parallel.py,
+ * mode "zero1"): vk_grad_sqnorm_chunks writes sums[c] = sum of squares of the 1024-element chunk c of g for c in [chunk0, chunk0 + nchunks)
+ * (0 for VK_CHUNK_SKIP chunks) -- a function of that chunk's data alone -- and vk_grad_norm_from_chunks adds all `total_chunks` sums in a
+ * fixed order (double) and leaves out[0..1] as vk_grad_norm_clip does.  A rank that computed only its own chunks and received the other
+ * ranks' sums obtains exactly the bits of a rank that computed them all. */
+int vk_grad_sqnorm_chunks(const float* g, int64_t chunk0, int64_t nchunks, const uint8_t* chunk_class, float* sums, vk_stream_t s);
+int vk_grad_norm_from_chunks(const float* sums, int64_t total_chunks, float pre_scale, float max_norm, float* out, vk_stream_t s);
 typedef struct vk_adamw_args {
     float* p;
     const float* g;
@@ -484,6 +505,9 @@ int vk_side_join(vk_stream_t s);
 int vk_side_join_from(vk_stream_t owner, vk_stream_t waiter);
 /* 0: run side-stream blocks inline on the caller's stream (serial schedule); 1 (default): concurrently. */
 void vk_side_enable(int on);
+/* Scheduling priority of side streams created AFTER the call, relative to the caller's stream: 0 = default priority, 1 = the
+   device's lowest (the weight-gradient blocks then only take the CUs the main chain leaves free).  Process-wide switch. */
+void vk_side_set_low_priority(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * ConceptCap batch producer: raw records -> the model's input tensors with the reference's sampling policy.

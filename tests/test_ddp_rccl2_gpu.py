@@ -60,6 +60,39 @@ def _worker(rank, world, port, shared_gpu=False):
         other = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(other, mine)
         assert all(torch.equal(o, other[0]) for o in other)
+        # ---- sharded optimizer (mode "zero1"): three training steps (clip + AdamW) against the unsharded wrapper from the same weights:
+        # master weights and bf16 copies bit-identical between the two paths and between the ranks, moments equal once gathered
+        from volta_amd.optimization import AdamW, clip_grad_norm_
+        runs = {}
+        for mode in ("allreduce", "zero1"):
+            m2, _, _ = build("vilbert")
+            m2.train()
+            m2.set_dropout_seed(1234)
+            ddp = DistributedDataParallel(m2, message_size=2000000, mode=mode)
+            opt = AdamW(m2.parameters(), lr=1e-3, weight_decay=0.01)
+            for step in range(3):
+                sum(ddp(*args_of(200 + 10 * step + rank))).sum().backward()
+                clip_grad_norm_(m2.parameters(), 0.5, defer_to_optimizer=True)      # small enough to be active
+                opt.step()
+                opt.zero_grad()
+            torch.cuda.synchronize()
+            sd = opt.state_dict()["state"]
+            runs[mode] = (m2._arena.master.clone(), m2._arena.shadow.clone(), torch.cat([sd[i]["exp_avg"].reshape(-1) for i in sorted(sd)]),
+                          torch.cat([sd[i]["exp_avg_sq"].reshape(-1) for i in sorted(sd)]), ddp.reducer.bytes_on_wire)
+            if mode == "zero1":
+                assert ddp.reducer.sharded, "no bucket was sharded"
+            m2.__dict__["_ddp"] = None
+        # (two ranks: a + b is the same sum in any order, the two paths agree bit for bit; with more ranks the collectives add a slot's
+        # `world` contributions in different ring orders -- last-bit differences of the averaged gradient, hence a tolerance)
+        for a, b2, what in zip(runs["allreduce"][:4], runs["zero1"][:4], ("master weights", "bf16 copies", "exp_avg", "exp_avg_sq")):
+            if world == 2:
+                assert torch.equal(a, b2), "zero1 vs unsharded: %s differ (max %g)" % (what, float((a.float() - b2.float()).abs().max()))
+            else:
+                assert float((a.float() - b2.float()).norm() / b2.float().norm()) <= 1e-5, what
+        mine = runs["zero1"][0]
+        other = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(other, mine)
+        assert all(torch.equal(o, other[0]) for o in other), "zero1: replicas differ"
     finally:
         dist.destroy_process_group()
 

@@ -1,4 +1,5 @@
-"""Size-independent properties of the pre-training step at BASELINE.json's FULL size (ctrl_vilbert_base, B=256, T=20, 36 regions),
+"""Size-independent properties of the pre-training step at BASELINE.json's FULL sizes -- configs[1] ctrl_vilbert_base B=256, configs[2]
+ctrl_lxmert B=256 and the per-GPU share of configs[3], ctrl_uniter_base B=512 (global batch 4096 over 8 GPUs); T=20, 36 regions --
 where the CPU oracle is too slow to be the checker:
   * pairs are independent: permuting the batch leaves the three losses and the gradients unchanged;
   * the losses are per-row means: the full-batch MLM / region / ITM losses are the count-weighted means of two half batches,
@@ -29,14 +30,14 @@ def _run(model, b, idx=None):
     return [float(lm.detach()), float(img.detach()), float(nsp.detach())], g, (n_lm, n_img, b["is_match"].shape[0])
 
 
-def test_full_size_batch_properties():
+@pytest.mark.parametrize("name,B", [("ctrl_vilbert_base", 256), ("ctrl_lxmert", 256), ("ctrl_uniter_base", 512)])
+def test_full_size_batch_properties(name, B):
     from volta_amd.config import BertConfig
     from volta_amd.modeling import BertForVLPreTraining
     from volta_amd.data import synthetic_batch
-    cfg = BertConfig.from_json_file(os.path.join(ROOT, "config", "ctrl_vilbert_base.json"))
+    cfg = BertConfig.from_json_file(os.path.join(ROOT, "config", name + ".json"))
     torch.manual_seed(1234)
     model = BertForVLPreTraining(cfg).cuda().eval()
-    B = 256
     b = synthetic_batch(cfg, B, 20, 36, seed=1234, device="cuda")
     full, g_full, n_full = _run(model, b)
     again, g_again, _ = _run(model, b)

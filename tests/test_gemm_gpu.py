@@ -10,7 +10,7 @@ def _mods():
     return L, ops
 
 
-GEOMETRIES = {"auto": 0, "tile128x128": 128, "tile256x256": 258, "tile256x192": 259, "tile256x128": 260,
+GEOMETRIES = {"auto": 0, "tile128x128": 128, "tile256x256": 258, "tile256x192": 259, "tile256x128": 260, "tile256x128_4wave": 261,
               "tile256x256_persistent": 258 | 0x1000, "tile256x192_persistent": 259 | 0x1000}
 
 
@@ -177,3 +177,76 @@ def test_gemm_nn_ragged_contraction_keeps_the_last_row(K):
     assert err <= 1e-2 * max(ref.abs().max().item(), 1.0), (K, err)
     last = (C[-1].float() - ref[-1]).abs().max().item()
     assert last <= 1e-2 * max(ref[-1].abs().max().item(), 1e-3), (K, "last row", last)
+
+
+@pytest.mark.parametrize("layout_name,M,N,K,nparts", [("NT", 700, 768, 3072, 3), ("NN", 1000, 768, 2304, 4), ("TN", 768, 768, 5120, 5),
+                                                      ("TN", 2304, 768, 2000, 2), ("NT", 256, 3072, 1024, 2)])
+def test_split_accumulation(layout_name, M, N, K, nparts, tile_edge):
+    """K-slices of one product in one launch: partial tiles through the workspace, the last arriver of a tile sums them in part order
+    and runs the epilogue (bias / residual / bias gradient once); bitwise reproducible, counters left at zero."""
+    if tile_edge != 0:
+        pytest.skip("the split path names its own geometry")
+    L, ops = _mods()
+    layout = getattr(L, layout_name)
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    if layout == L.NT:
+        A, B = rnd((M, K), g, 0.5), rnd((N, K), g, 0.1)
+    elif layout == L.NN:
+        A, B = rnd((M, K), g, 0.5), rnd((K, N), g, 0.1)
+    else:
+        A, B = rnd((K, M), g, 0.5), rnd((K, N), g, 0.1)
+    geo = ops.split_geometry(N)
+    ws, cnt = ops.split_workspace(layout, M, N, nparts, geo, "cuda")
+    ws.fill_(0xFF)                                          # NaN patterns: every word the reducer reads must have been written
+    if layout == L.TN:
+        epi, bias, R = L.EPI_F32, None, None
+        Cb = torch.full((M, N), float("nan"), device="cuda")
+        bg = torch.full((M,), float("nan"), device="cuda")
+    else:
+        epi = L.EPI_ADDR
+        bias, R = torch.randn(N, generator=g, device="cuda"), rnd((M, N), g)
+        Cb = torch.zeros(M, N, device="cuda", dtype=torch.bfloat16)
+        bg = None
+    whole = ops.gemm_problem(A, B, Cb, layout, M, N, K, bias=bias, R=R, bias_grad=bg)
+    slices = ops.k_slices(A, B, layout, K, nparts)
+    assert len(slices) == nparts
+    parts = ops.split_parts(whole, layout, slices, ws, cnt)
+    ops.gemm_grouped(layout, epi, parts, geometry=geo)
+    torch.cuda.synchronize()
+    first = Cb.clone()
+    ref = ref_mm(layout, A, B, L)
+    if layout == L.TN:
+        assert (Cb - ref).abs().max().item() <= 2e-3 * max(ref.abs().max().item(), 1.0)
+        assert (bg - A.float().sum(0)).abs().max().item() <= 2e-3 * max(A.float().sum(0).abs().max().item(), 1.0)
+    else:
+        want = ref + bias + R.float()
+        assert ((Cb.float() - want).abs() <= 1e-2 * want.abs() + 2e-2).all()
+    assert int(cnt.abs().sum()) == 0, "every tile's counter must be back at zero"
+    for _ in range(3):                                      # same bits whoever arrives last
+        Cb.zero_()
+        ops.gemm_grouped(layout, epi, parts, geometry=geo)
+        torch.cuda.synchronize()
+        assert torch.equal(Cb, first)
+    # the parts of another product in the same launch do not disturb it
+    ws2, cnt2 = ops.split_workspace(layout, M, N, nparts, geo, "cuda")
+    C2b = torch.zeros_like(Cb)
+    bg2 = torch.zeros_like(bg) if bg is not None else None
+    whole2 = ops.gemm_problem(A, B, C2b, layout, M, N, K, bias=bias, R=R, bias_grad=bg2)
+    both = parts + ops.split_parts(whole2, layout, slices, ws2, cnt2)
+    Cb.zero_()
+    ops.gemm_grouped(layout, epi, both, geometry=geo)
+    torch.cuda.synchronize()
+    assert torch.equal(Cb, first) and torch.equal(C2b, first)
+
+
+def test_split_accumulation_rejects_incomplete_groups():
+    L, ops = _mods()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    A, B = rnd((256, 512), g), rnd((256, 512), g)
+    Cb = torch.zeros(256, 256, device="cuda", dtype=torch.bfloat16)
+    ws, cnt = ops.split_workspace(L.NT, 256, 256, 2, 258, "cuda")
+    parts = ops.split_parts(ops.gemm_problem(A, B, Cb, L.NT, 256, 256, 512), L.NT, ops.k_slices(A, B, L.NT, 512, 2), ws, cnt)
+    with pytest.raises(RuntimeError):
+        ops.gemm_grouped(L.NT, L.EPI_BF16, parts[:1], geometry=258)      # a part is missing
+    with pytest.raises(RuntimeError):
+        ops.gemm_grouped(L.NT, L.EPI_BF16, parts, geometry=128)          # not a 256-row geometry

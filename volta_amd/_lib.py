@@ -46,7 +46,7 @@ def rng_cfg(seed_ptr, site):
 class GemmProblem(C.Structure):
     _fields_ = [("A", c_p), ("B", c_p), ("C", c_p), ("C2", c_p), ("bias", c_p), ("R", c_p), ("bias_grad", c_p),
                 ("dyn", c_p), ("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32), ("ldc", i32),
-                ("ldr", i32), ("n_store", i32)]
+                ("ldr", i32), ("n_store", i32), ("ws", c_p), ("cnt", c_p), ("part", i32), ("nparts", i32)]
 
 
 class GemmFp8Problem(C.Structure):
@@ -179,6 +179,7 @@ _sig("vk_gemm_fp8_grouped", C.c_int, C.c_int, C.POINTER(GemmFp8Problem), C.c_int
 _sig("vk_quant_rows_fp8", C.c_int, c_p, C.c_int, C.c_int64, c_p, C.c_int64, c_p, C.c_int, C.c_int, c_p, c_p)
 _sig("vk_cast_bf16_fp8", C.c_int, c_p, c_p, C.c_int64, C.c_float, c_p)
 _sig("vk_gemm_grouped_ex", C.c_int, C.c_int, C.c_int, C.POINTER(GemmProblem), C.c_int, C.c_int, c_p)
+_sig("vk_gemm_split_workspace_bytes", C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int))
 _sig("vk_gated_attn_fwd", C.c_int, C.POINTER(AttnArgs), c_p)
 _sig("vk_gated_attn_bwd", C.c_int, C.POINTER(AttnArgs), C.POINTER(AttnBwdArgs), c_p)
 _sig("vk_ln_fwd", C.c_int, C.POINTER(LnArgs), c_p)
@@ -235,6 +236,8 @@ _sig("vk_grad_norm_workspace_floats", C.c_int)
 _sig("vk_grad_norm_clip", C.c_int, c_p, C.c_int64, C.c_float, C.c_float, c_p, c_p, c_p)
 _sig("vk_adamw_step", C.c_int, C.POINTER(AdamwArgs), c_p)
 _sig("vk_grad_norm_clip_masked", C.c_int, c_p, C.c_int64, c_p, C.c_float, C.c_float, c_p, c_p, c_p)
+_sig("vk_grad_sqnorm_chunks", C.c_int, c_p, C.c_int64, C.c_int64, c_p, c_p, c_p)
+_sig("vk_grad_norm_from_chunks", C.c_int, c_p, C.c_int64, C.c_float, C.c_float, c_p, c_p)
 _sig("vk_axpy_f32", C.c_int, c_p, c_p, C.c_float, C.c_int64, c_p)
 _sig("vk_sum_slabs_f32", C.c_int, c_p, c_p, C.c_int64, C.c_int, C.c_int64, c_p)
 _sig("vk_sum_slabs_bf16", C.c_int, c_p, c_p, C.c_int64, C.c_int, C.c_int64, c_p, C.c_int, c_p)
@@ -249,16 +252,17 @@ _sig("vk_concap_batch", C.c_int, C.POINTER(ConcapArgs), c_p)
 _sig("vk_side_join", C.c_int, c_p)
 _sig("vk_side_join_from", C.c_int, c_p, c_p)
 _sig("vk_side_enable", None, C.c_int)
+_sig("vk_side_set_low_priority", None, C.c_int)
 
-EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_cast_f32_bf16", "vk_gemm_grouped", "vk_gemm_grouped_ex", "vk_gemm_fp8_grouped", "vk_quant_rows_fp8", "vk_cast_bf16_fp8",
+EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_cast_f32_bf16", "vk_gemm_grouped", "vk_gemm_grouped_ex", "vk_gemm_split_workspace_bytes", "vk_gemm_fp8_grouped", "vk_quant_rows_fp8", "vk_cast_bf16_fp8",
            "vk_ln_fwd", "vk_ln_fwd_pair", "vk_ln_bwd_partial_rows", "vk_ln_bwd", "vk_ln_bwd_pair", "vk_ln_bwd_finalize", "vk_gated_attn_fwd", "vk_gated_attn_bwd",
            "vk_embed_sum_fwd", "vk_embed_sum_bwd", "vk_rows32", "vk_loc_linear_fwd", "vk_loc_linear_bwd",
            "vk_add_dropout", "vk_colsum_bf16", "vk_vlbert_prep_fwd", "vk_vlbert_maskgrad", "vk_rowgroup_sum_bf16",
            "vk_relu_bwd_bf16", "vk_copy_async", "vk_select_rows", "vk_gather_rows", "vk_scatter_rows_add", "vk_xent_fwd",
            "vk_xent_bwd", "vk_kl_fwd", "vk_kl_bwd", "vk_loss_finalize", "vk_pool_mul_fwd", "vk_pool_mul_bwd",
            "vk_pool_fuse_fwd", "vk_pool_fuse_bwd", "vk_text_end_rows", "vk_vlbert_obj_ids", "vk_vlbert_positions", "vk_vis_loss_fwd", "vk_vis_loss_bwd", "vk_nce_negatives",
-           "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_grad_norm_clip_masked", "vk_adamw_step",
-           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_side_tail", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_join_from", "vk_side_enable", "vk_concap_batch",
+           "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_grad_norm_clip_masked", "vk_grad_sqnorm_chunks", "vk_grad_norm_from_chunks", "vk_adamw_step",
+           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_side_tail", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_join_from", "vk_side_enable", "vk_side_set_low_priority", "vk_concap_batch",
            "vk_lmdb_open", "vk_lmdb_close", "vk_lmdb_entries", "vk_lmdb_first", "vk_lmdb_next", "vk_lmdb_get", "vk_concap_record_decode", "vk_concap_records_decode", "vk_b64_decode",
            "vk_wordpiece_open", "vk_wordpiece_close", "vk_wordpiece_vocab_size", "vk_wordpiece_token_id", "vk_wordpiece_encode", "vk_wordpiece_encode_batch"]
 

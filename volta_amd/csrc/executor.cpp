@@ -26,6 +26,7 @@ struct Side {
 std::mutex g_side_mutex;
 std::unordered_map<void*, Side*> g_sides;
 int g_side_enabled = 1;
+int g_side_low_priority = 0;
 
 Side* side_lookup(vk_stream_t caller) {
     std::lock_guard<std::mutex> lock(g_side_mutex);
@@ -39,7 +40,9 @@ Side* side_for(vk_stream_t caller) {
     if (sp && sp->ok) return sp;
     if (!sp) sp = new Side();
     Side& g = *sp;
-    if (hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) != hipSuccess) { vk::set_error("side stream: hipStreamCreate failed"); return nullptr; }
+    int prio_least = 0, prio_greatest = 0;
+    if (g_side_low_priority) (void)hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+    if (hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, g_side_low_priority ? prio_least : 0) != hipSuccess) { vk::set_error("side stream: hipStreamCreate failed"); return nullptr; }
     if (hipEventCreateWithFlags(&g.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g.join, hipEventDisableTiming) != hipSuccess) {
         vk::set_error("side stream: hipEventCreate failed");
         return nullptr;
@@ -52,6 +55,7 @@ Side* side_for(vk_stream_t caller) {
 }  // namespace
 
 extern "C" void vk_side_enable(int on) { g_side_enabled = on; }
+extern "C" void vk_side_set_low_priority(int on) { g_side_low_priority = on; }
 
 extern "C" int vk_side_join_from(vk_stream_t owner, vk_stream_t waiter) {
     Side* g = side_lookup(owner);
@@ -132,7 +136,7 @@ static int run_one(const vk_op& o, int i, vk_stream_t s) {
     {
         int rc = 0;
         switch (o.kind) {
-            case VK_OP_GEMM: rc = vk_gemm_grouped(o.i0, o.i1, (const vk_gemm_problem*)o.a, o.i2, s); break;
+            case VK_OP_GEMM: rc = vk_gemm_grouped_ex(o.i0 & 0xFF, o.i1, (const vk_gemm_problem*)o.a, o.i2, o.i0 >> 8, s); break;      /* i0: layout | tile geometry << 8 (0 = heuristic) */
             case VK_OP_GEMM_FP8: rc = vk_gemm_fp8_grouped(o.i1, (const vk_gemm_fp8_problem*)o.a, o.i2, o.i0, s); break;
             case VK_OP_LN_FWD: rc = vk_ln_fwd_pair((const vk_ln_args*)o.a, (const vk_ln_args*)o.b, s); break;
             case VK_OP_LN_BWD: rc = vk_ln_bwd_pair((const vk_ln_bwd_args*)o.a, (const vk_ln_bwd_args*)o.b, s); break;

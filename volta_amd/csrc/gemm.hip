@@ -250,7 +250,7 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
     using namespace vk;
     if (nprob < 1 || nprob > VK_GEMM_MAX_GROUP) return set_error("vk_gemm_grouped: nprob %d out of range", nprob);
     const bool f32out = epilogue == VK_EPI_F32 || epilogue == VK_EPI_F32_ACC;
-    bool any_dyn = false;
+    bool any_dyn = false, any_split = false;
     for (int i = 0; i < nprob; ++i) {
         const vk_gemm_problem& q = probs[i];
         if (q.M < 0 || q.N <= 0 || q.K < 0) return set_error("vk_gemm_grouped: bad shape %d %d %d", q.M, q.N, q.K);
@@ -263,6 +263,20 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
         if ((epilogue == VK_EPI_MULR || epilogue == VK_EPI_ADDR) && !q.R) return set_error("vk_gemm_grouped: R missing");
         if (epilogue == VK_EPI_GELU && !q.C2) return set_error("vk_gemm_grouped: C2 missing");
         any_dyn |= q.dyn != nullptr;
+        any_split |= q.nparts > 1;
+        if (q.nparts > 1) {
+            if (!q.ws || !q.cnt || q.part < 0 || q.part >= q.nparts) return set_error("vk_gemm_grouped: split accumulation needs ws, cnt and 0 <= part < nparts");
+            if (q.dyn) return set_error("vk_gemm_grouped: split accumulation does not take a device-side row count");
+            if (((uintptr_t)q.ws & 15)) return set_error("vk_gemm_grouped: ws must be 16-byte aligned");
+            int seen = 0;
+            for (int j = 0; j < nprob; ++j)
+                if (probs[j].ws == q.ws && probs[j].nparts > 1) {
+                    if (probs[j].M != q.M || probs[j].N != q.N || probs[j].C != q.C || probs[j].cnt != q.cnt || probs[j].nparts != q.nparts)
+                        return set_error("vk_gemm_grouped: the parts of one split accumulation must agree in M, N, C, cnt and nparts");
+                    seen |= 1 << probs[j].part;
+                }
+            if (q.nparts > 30 || seen != (1 << q.nparts) - 1) return set_error("vk_gemm_grouped: a split accumulation needs each of its %d parts exactly once in the launch", q.nparts);
+        }
     }
 #ifdef VK_STUDY
     static const bool env_once = [] {       // tuning overrides from the environment (study builds only)
@@ -291,15 +305,16 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
             edge = c192 < 0.97 * c256 ? 259 : 258;
         }
     }
-    if (edge == 256 || edge == 258 || edge == 259 || edge == 260) {
+    if (edge == 256 || edge == 258 || edge == 259 || edge == 260 || edge == 261) {
         for (int i = 0; i < nprob; ++i) {
             const vk_gemm_problem& q = probs[i];
             const uint64_t ea = (uint64_t)(layout == VK_TN ? q.K : q.M) * q.lda * 2, eb = (uint64_t)(layout == VK_NT ? q.N : q.K) * q.ldb * 2;
             if (ea >= 0x7FFFFFF0ull || eb >= 0x7FFFFFF0ull) { edge = 128; break; }     // the LDS-DMA kernels address operands below 2 GiB
         }
     }
-    if (edge != 256 && edge != 258 && edge != 259 && edge != 260) edge = 128;
-    const int bm = edge == 128 ? 128 : 256, bn = edge == 259 ? 192 : edge == 260 ? 128 : bm;
+    if (edge != 256 && edge != 258 && edge != 259 && edge != 260 && edge != 261) edge = 128;
+    if (any_split && edge != 258 && edge != 259) return set_error("vk_gemm_grouped: split accumulation runs on the 256 x 256 / 256 x 192 geometries (258 / 259), got %d", geometry & 0xFFF);
+    const int bm = edge == 128 ? 128 : 256, bn = edge == 259 ? 192 : (edge == 260 || edge == 261) ? 128 : bm;
     KGroup g;
     g.nprob = nprob;
     g.stagger = (g_stagger & 0xFF) | ((g_debug & 0xFF) << 8);
@@ -313,6 +328,7 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
         k.A = (const char*)q.A; k.B = (const char*)q.B; k.C = (char*)q.C; k.C2 = (char*)q.C2; k.bias = q.bias;
         k.R = (const char*)q.R; k.bias_grad = q.bias_grad; k.dyn = q.dyn; k.C8 = nullptr; k.c8_mul = 0.f; k.ldc8 = 0;
         k.M = q.M; k.N = q.N; k.K = q.K; k.lda = q.lda; k.ldb = q.ldb; k.ldc = q.ldc; k.ldr = q.ldr; k.n_store = q.n_store;
+        k.ws = (char*)q.ws; k.cnt = q.cnt; k.part = q.part; k.nparts = q.nparts;
         const int ncols = (f32out && q.n_store > q.N) ? q.n_store : q.N;
         k.tiles_n = (ncols + bn - 1) / bn;
         k.tile_start = total;
@@ -320,10 +336,11 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
     }
     if (total == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (edge == 261) return launch_gemm4w(layout, epilogue, g, total, s);      // half-CU tiles: two workgroups per CU
     if (edge == 256 || edge == 258 || edge == 259 || edge == 260) {
         // more than one round of tiles: one workgroup per CU walks the list (gemm256p_kernel); device-side row counts keep the
         // one-tile-per-workgroup launch (dead tiles exit at once there)
-        bool persistent = (edge == 258 || edge == 259) && layout != VK_TN && !any_dyn;
+        bool persistent = (edge == 258 || edge == 259) && layout != VK_TN && !any_dyn && !any_split;
         if (walk == VK_GEMM_PERSISTENT) persistent = persistent && true;
         else if (walk == VK_GEMM_ONE_TILE_PER_WG) persistent = false;
         else persistent = persistent && g_persistent && total > NUM_CU;
@@ -336,6 +353,19 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
         if (layout == VK_TN) return reg ? launch_cfg<true, true, 2, 2, true>(epilogue, g, total, s) : launch_cfg<true, true, 2, 2, false>(epilogue, g, total, s);
     }
     return set_error("vk_gemm_grouped: unknown layout %d", layout);
+}
+
+extern "C" size_t vk_gemm_split_workspace_bytes(int layout, int M, int N, int nparts, int geometry, int* tiles) {
+    const int edge = geometry & 0xFFF;
+    if ((edge != 258 && edge != 259) || M <= 0 || N <= 0 || nparts < 2) {
+        if (tiles) *tiles = 0;
+        return 0;
+    }
+    const int bn = edge == 259 ? 192 : 256, tj = bn / 64;
+    const int nt = ((M + 255) / 256) * ((N + bn - 1) / bn);
+    if (tiles) *tiles = nt;
+    const size_t per = (size_t)8 * (size_t)(8 * tj + (layout == VK_TN ? 8 : 0)) * 1024u;       // split_slab_bytes<8, TJ, BG>(8)
+    return (size_t)nt * (size_t)nparts * per;
 }
 
 extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, vk_stream_t stream) {

@@ -359,6 +359,10 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     VK_SYNC();
 
+    if (P.nparts > 1) {            // K-slice of a split accumulation: only the workgroup that arrives last at the tile goes on
+        if (!split_combine<8, TJ, BG, 8>(P, t, acc, accb, wave, lane, lds0)) return;
+        __syncthreads();           // the ticket word lies in wave 0's staging region
+    }
     gemm_epilogue<AT, EPI, 8, TJ>(P, acc, accb, do_bias_grad, m0 + wr * 128, n0 + wc * WN, M, lane, lds0 + (uint32_t)wave * 16384u);
 }
 

@@ -15,6 +15,7 @@ struct KProb {
     int32_t M, N, K, lda, ldb, ldc, ldr, n_store;
     int32_t tiles_n, tile_start;
     char* C8; float c8_mul; int32_t ldc8;      // GELU epilogue (fp8 path): e4m3 copy of C, q = saturate(C * c8_mul); NULL otherwise
+    char* ws; int32_t* cnt; int32_t part, nparts;   // split accumulation (vk_gemm_problem): nparts <= 1 = off
 };
 constexpr int GROUP_PLAIN_ORDER = 1 << 16;    // KGroup::stagger flag: workgroup i takes tile i (no XCD chunking)
 struct KGroup {
@@ -300,9 +301,78 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
     }
 }
 
+// ---- split accumulation: nparts workgroups hold K-slices of one output tile (include/volta_hip.h, vk_gemm_problem::ws) -------------
+// Every workgroup stores its accumulators into its slab of `ws` with write-through (sc1) 16-byte stores, drains them
+// (s_waitcnt vmcnt(0) in every wave, workgroup barrier) and ONE lane draws a ticket from the tile's counter with an agent-scope
+// atomic add; the workgroup whose add came last (ticket = nparts - 1) reads all slabs back with sc1 loads -- in part order, its own
+// included, so that the fp32 sum does not depend on who arrived last -- resets the counter and returns true: it runs the epilogue.
+// (The hand-off form is MI355X_MICROARCH.md's "valid forms" table, first row: one lane per storing workgroup adds to one counter, the
+// adder that came last is told by the value its add returned, its other waves load behind a workgroup barrier; sc1 stores and loads of
+// 16 bytes, hipMalloc memory, one workgroup per CU.)  Nobody waits for anybody: the launch completes under any residency.
+// Slab layout: [wave][value index][lane] f32x4, value index = i * TJ + j (accumulator tiles), then TI bias-gradient tiles when BG.
+template <int TI, int TJ, bool BG> constexpr uint32_t split_slab_bytes(int waves) { return (uint32_t)waves * (uint32_t)(TI * TJ + (BG ? TI : 0)) * 1024u; }
+
+template <int TI, int TJ, bool BG, int WAVES>
+__device__ __forceinline__ bool split_combine(const KProb& P, int tile, f32x4 (&acc)[TI][TJ], f32x4 (&accb)[TI], int wave, int lane, uint32_t lds_word) {
+    constexpr int NV = TI * TJ + (BG ? TI : 0);
+    constexpr uint32_t WAVE_BYTES = NV * 1024u, SLAB = WAVES * WAVE_BYTES;
+    char* const tile_ws = P.ws + (size_t)tile * (size_t)P.nparts * SLAB;
+    const uint32_t base = (uint32_t)wave * WAVE_BYTES + (uint32_t)lane * 16u;
+    {
+        const __amdgpu_buffer_rsrc_t rw = make_rsrc(tile_ws + (size_t)P.part * SLAB, SLAB);
+#pragma unroll
+        for (int i = 0; i < TI; ++i)
+#pragma unroll
+            for (int j = 0; j < TJ; ++j)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, acc[i][j]), rw, base + (uint32_t)(i * TJ + j) * 1024u, 0, 16 /* sc1: write-through */);
+        if (BG) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, accb[i]), rw, base + (uint32_t)(TI * TJ + i) * 1024u, 0, 16);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave, before the barrier the ticket lane passes
+    __syncthreads();
+    volatile uint32_t VK_LDS* const word = (volatile uint32_t VK_LDS*)(uintptr_t)lds_word;
+    if (threadIdx.x == 0) {
+        const int ticket = __hip_atomic_fetch_add(P.cnt + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *word = (uint32_t)ticket;                             // the add has returned: its value is used
+    }
+    __syncthreads();
+    const int ticket = (int)*word;
+    if (ticket != P.nparts - 1) return false;
+#pragma unroll
+    for (int i = 0; i < TI; ++i) {
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (BG) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma nounroll
+    for (int q = 0; q < P.nparts; ++q) {
+        const __amdgpu_buffer_rsrc_t rq = make_rsrc(tile_ws + (size_t)q * SLAB, SLAB);
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            u32x4 v[TJ];
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) v[j] = __builtin_amdgcn_raw_buffer_load_b128(rq, base + (uint32_t)(i * TJ + j) * 1024u, 0, 16 /* sc1 */);
+#pragma unroll
+            for (int j = 0; j < TJ; ++j) acc[i][j] += __builtin_bit_cast(f32x4, v[j]);
+        }
+        if (BG) {
+#pragma unroll
+            for (int i = 0; i < TI; ++i)
+                accb[i] += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rq, base + (uint32_t)(TI * TJ + i) * 1024u, 0, 16));
+        }
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(P.cnt + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+    return true;
+}
+
 // 256-row tiles, 8 waves, LDS-DMA ring (gemm256.hip).  variant 4 / 3 / 2: K-split kernel with 256 / 192 / 128 columns; 0: the 4-phase
 // study kernel (VK_STUDY builds only).  persistent: one workgroup per CU walks the tile list (NT / NN, no device-side row counts).
 constexpr int NUM_CU = 256;       // MI355X
 int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant, bool persistent);
+// 256 x 128 tiles, 4 waves, 72 KiB LDS: two workgroups per CU (gemm4w.hip)
+int launch_gemm4w(int layout, int epilogue, const KGroup& g, int total, hipStream_t s);
 
 }  // namespace vk

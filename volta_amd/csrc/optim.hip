@@ -44,6 +44,42 @@ __global__ __launch_bounds__(256) void sqnorm_final_kernel(const float* partial,
     }
 }
 
+// shard-decomposable norm: one wave per 1024-element chunk, lanes sum 4 x float4 in a fixed order
+__global__ __launch_bounds__(256) void sqnorm_chunks_kernel(const float* g, size_t chunk0, size_t nchunks, const uint8_t* chunk_class, float* sums) {
+    const size_t c = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (c >= nchunks) return;
+    const size_t chunk = chunk0 + c;
+    const int lane = threadIdx.x & 63;
+    float s = 0.f;
+    if (!(chunk_class && chunk_class[chunk] == VK_CHUNK_SKIP)) {
+        const float* p = g + chunk * 1024;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const f32x4 v = *(const f32x4*)(p + (k * 64 + lane) * 4);
+            s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+        }
+    }
+    s = wave_sum(s);
+    if (lane == 0) sums[chunk] = s;
+}
+__global__ __launch_bounds__(1024) void sqnorm_from_chunks_kernel(const float* sums, size_t n, float pre_scale, float max_norm, float* out) {
+    __shared__ double sh[16];
+    double s = 0.0;
+    for (size_t i = threadIdx.x; i < n; i += 1024) s += (double)sums[i];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+        for (int i = 0; i < 16; ++i) t += sh[i];
+        const float norm = (float)sqrt(t) * pre_scale;
+        out[0] = norm;
+        float coef = 1.f;
+        if (max_norm > 0.f) { coef = max_norm / (norm + 1e-6f); if (coef > 1.f) coef = 1.f; }
+        out[1] = coef;
+    }
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(vk_adamw_args a) {
     const size_t chunk = blockIdx.x;
     const int cls = a.chunk_class ? a.chunk_class[chunk] : 0;
@@ -218,6 +254,19 @@ extern "C" int vk_grad_norm_clip_masked(const float* g, int64_t n, const uint8_t
     hipLaunchKernelGGL(sqnorm_partial_kernel, dim3(NORM_BLOCKS), dim3(256), 0, st, g, (size_t)(n / 4), partial, chunk_class);
     hipLaunchKernelGGL(sqnorm_final_kernel, dim3(1), dim3(256), 0, st, partial, NORM_BLOCKS, pre_scale, max_norm, out);
     return check_launch("vk_grad_norm_clip");
+}
+
+extern "C" int vk_grad_sqnorm_chunks(const float* g, int64_t chunk0, int64_t nchunks, const uint8_t* chunk_class, float* sums, vk_stream_t s) {
+    if (chunk0 < 0 || nchunks < 0 || ((uintptr_t)g & 15)) return set_error("vk_grad_sqnorm_chunks: bad range or alignment");
+    if (nchunks == 0) return 0;
+    hipLaunchKernelGGL(sqnorm_chunks_kernel, dim3((unsigned)((nchunks + 3) / 4)), dim3(256), 0, (hipStream_t)s, g, (size_t)chunk0, (size_t)nchunks, chunk_class, sums);
+    return check_launch("vk_grad_sqnorm_chunks");
+}
+
+extern "C" int vk_grad_norm_from_chunks(const float* sums, int64_t total_chunks, float pre_scale, float max_norm, float* out, vk_stream_t s) {
+    if (total_chunks <= 0) return set_error("vk_grad_norm_from_chunks: no chunks");
+    hipLaunchKernelGGL(sqnorm_from_chunks_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, sums, (size_t)total_chunks, pre_scale, max_norm, out);
+    return check_launch("vk_grad_norm_from_chunks");
 }
 
 extern "C" int vk_grad_norm_clip(const float* g, int64_t n, float pre_scale, float max_norm, float* partial, float* out, vk_stream_t s) {

@@ -317,13 +317,57 @@ class StepEngine:
     def G(self, name):
         return self.arena.view(name, "grad")
 
-    def gemm(self, plan_ops, layout, epi, probs):
+    def gemm(self, plan_ops, layout, epi, probs, geometry=0):
+        """geometry: tile code of vk_gemm_grouped_ex carried in the op's i0 above the layout (0 = the library's heuristic)"""
         arr = self.k((L.GemmProblem * len(probs))(*probs))
-        plan_ops.append((L.OP_GEMM, layout, epi, len(probs), arr, None, None))
+        plan_ops.append((L.OP_GEMM, layout | (geometry << 8), epi, len(probs), arr, None, None))
 
     def prob(self, A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, C2=None, bias_grad=None, dyn=None, n_store=0):
         return L.GemmProblem(_addr(A), _addr(B), _addr(Cout), _addr(C2), _addr(bias), _addr(R), _addr(bias_grad), _addr(dyn),
                              M, N, K, lda, ldb, ldc, ldr, n_store)
+
+    # ---- split accumulations (include/volta_hip.h, vk_gemm_problem::ws): K-slices of one product in one launch, summed by the last arriver
+    SPLIT_WS_CAP = 768 << 20         # bytes of partial-tile workspace per stream (launches on one stream are ordered: they share it)
+
+    def _split_alloc(self, tag, layout, M, N, nparts, geometry):
+        """(ws address, cnt address) for one split accumulation of the launch being built on stream `tag` ("main" / "side")."""
+        tiles = C.c_int(0)
+        nbytes = L.lib.vk_gemm_split_workspace_bytes(layout, M, N, nparts, geometry, C.byref(tiles))
+        assert nbytes > 0 and tiles.value > 0, (layout, M, N, nparts, geometry)
+        aside, self._aside = getattr(self, "_aside", ""), ""          # the arenas belong to a stream, not to a block of ops
+        ws = self.tmp("split_ws_" + tag, (self.SPLIT_WS_CAP,), torch.uint8)
+        self._aside = aside
+        if "split_cnt_" + tag not in self.bufs:
+            self.bufs["split_cnt_" + tag] = torch.zeros(1 << 16, dtype=torch.int32, device=self.dev)      # zero once: every launch leaves them zero
+        cnt = self.bufs["split_cnt_" + tag]
+        cur = self.__dict__.setdefault("_split_cur", {}).setdefault(tag, [0, 0])
+        assert cur[0] + nbytes <= self.SPLIT_WS_CAP and cur[1] + tiles.value <= cnt.numel(), "split workspace too small"
+        out = (ws.data_ptr() + cur[0], cnt.data_ptr() + 4 * cur[1])
+        cur[0] += _round_up(nbytes, 256)
+        cur[1] += tiles.value
+        return out
+
+    def _split_launch_done(self, tag):
+        self.__dict__.setdefault("_split_cur", {})[tag] = [0, 0]
+
+    @staticmethod
+    def split_geometry(widths):
+        """One tile geometry for a launch whose outputs are `widths` columns wide: 256 x 192 tiles when they cover every width without a
+        ragged column tile and 256-wide ones would not (N = 768), 256 x 256 otherwise."""
+        return 259 if all(n % 192 == 0 for n in widths) and any(n % 256 for n in widths) else 258
+
+    def prob_parts(self, tag, geometry, layout, slices, Cout, M, N, ldc, **kw):
+        """The problems of ONE product cut into len(slices) parts; slices: [(A address, B address, K, lda, ldb)]."""
+        if len(slices) == 1:
+            A, B, K, lda, ldb = slices[0]
+            return [self.prob(A, B, Cout, M, N, K, lda, ldb, ldc, **kw)]
+        ws, cnt = self._split_alloc(tag, layout, M, N, len(slices), geometry)
+        out = []
+        for i, (A, B, K, lda, ldb) in enumerate(slices):
+            q = self.prob(A, B, Cout, M, N, K, lda, ldb, ldc, **kw)
+            q.ws, q.cnt, q.part, q.nparts = ws, cnt, i, len(slices)
+            out.append(q)
+        return out
 
     def gemm_fp8(self, plan_ops, epi, specs):
         """specs: [(A bf16 [M, K] or (A8, scale_a) already quantised, master weight view [N, K], C, bias, C2)] -- one fp8 launch for all of
@@ -563,7 +607,15 @@ class StepEngine:
 
     def _img_proj_bwd(self, b, pre, wname, dz, featb):
         st, H, F_ = self.st[1], self.st[1].H, self.cfg.v_feature_size
-        self.gemm(b, L.TN, L.EPI_F32, [self.prob(dz, featb, self.G(pre + wname + ".weight"), H, F_, st.M, H, F_, F_, bias_grad=self.G(pre + wname + ".bias"))])
+        # [H x F] output (24 tiles of 256 x 256) over B * Rv rows: row chunks as parts of one split accumulation fill the chip (146 -> 87 us, profiles/r03_ops_per_launch.txt)
+        nparts = max(1, min(8, st.M // 1024))
+        step = _round_up(-(-st.M // nparts), 64)
+        tag = "side" if getattr(self, "_aside", "") else "main"
+        geo = self.split_geometry([F_])
+        slices = [(_addr(dz[r0:]), _addr(featb[r0:]), min(step, st.M - r0), H, F_) for r0 in range(0, st.M, step)]
+        probs = self.prob_parts(tag, geo, L.TN, slices, self.G(pre + wname + ".weight"), H, F_, F_, bias_grad=self.G(pre + wname + ".bias"))
+        self.gemm(b, L.TN, L.EPI_F32, probs, geometry=geo if len(probs) > 1 else 0)
+        self._split_launch_done(tag)
 
     def _loc_proj_bwd(self, b, pre, dz):
         st, H = self.st[1], self.st[1].H

@@ -46,6 +46,47 @@ def gemm_problem(A, B, Cout, layout, M, N, K, bias=None, R=None, C2=None, bias_g
                          M, N, K, lda, ldb, ldc, ldr or 0, n_store)
 
 
+def split_geometry(N):
+    """Tile geometry a split accumulation runs on: 256 x 192 tiles when they cover N without a ragged last column tile and 256-wide ones
+    would not (N = 768: 4 x 192), 256 x 256 otherwise."""
+    return 259 if (N % 192 == 0 and N % 256 != 0) else 258
+
+
+def split_workspace(layout, M, N, nparts, geometry, device):
+    """(ws uint8 tensor, cnt int32 tensor) of one split accumulation; cnt starts (and is left by every launch) at zero."""
+    tiles = C.c_int(0)
+    nbytes = L.lib.vk_gemm_split_workspace_bytes(layout, M, N, nparts, geometry, C.byref(tiles))
+    assert nbytes > 0, "split accumulation: nparts >= 2 and geometry 258 / 259"
+    return torch.empty(nbytes, dtype=torch.uint8, device=device), torch.zeros(tiles.value, dtype=torch.int32, device=device)
+
+
+def split_parts(problem, layout, slices, ws, cnt):
+    """K-slices of ONE product as the problems of a split accumulation.  `problem`: the whole product (gemm_problem); `slices`: list of
+    (A view, B view, K) -- operand pointers and contraction length of each part (a part may come from other tensors altogether: the
+    weight gradient of a parameter shared by two modalities sums row chunks of both)."""
+    out = []
+    for i, (A, B, K) in enumerate(slices):
+        q = L.GemmProblem.from_buffer_copy(problem)
+        q.A, q.B, q.K = ptr(A), ptr(B), K
+        q.ws, q.cnt, q.part, q.nparts = ptr(ws), ptr(cnt), i, len(slices)
+        out.append(q)
+    return out
+
+
+def k_slices(A, B, layout, K, nparts, lda=None, ldb=None):
+    """Even K-slices (multiples of 64 elements / rows) of the operands of one product, for split_parts()."""
+    step = -(-K // nparts)
+    step = -(-step // 64) * 64
+    out, k0 = [], 0
+    while k0 < K:
+        kc = min(step, K - k0)
+        a = A[k0:] if layout == L.TN else A[:, k0:]
+        b = B[:, k0:] if layout == L.NT else B[k0:]
+        out.append((a, b, kc))
+        k0 += step
+    return out
+
+
 default_geometry = 0      # what gemm_grouped() passes when the caller names none (the parity tests sweep it; 0 = the library's heuristic)
 
 

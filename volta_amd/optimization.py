@@ -153,12 +153,44 @@ class AdamW(Optimizer):
         a.step_mult = math.sqrt(1.0 - b2 ** t) / (1.0 - b1 ** t) if g0["correct_bias"] else 1.0
         a.grad_scale = grad_scale
         arena.sync_optimizer()         # an earlier pipelined step nobody waited for (two steps without a forward in between)
-        if not self._overlap[0]:
+        red = self._zero1_reducer()
+        if red is not None:
+            self._step_zero1(a, arena, red)
+        elif not self._overlap[0]:
             L.check(L.lib.vk_adamw_step(C.byref(a), L.stream_ptr()))
         else:
             self._step_pipelined(a, arena, clip)
         arena.mark_shadow_fresh()      # the kernel refreshed the bf16 copies itself
         return loss
+
+    def _zero1_reducer(self):
+        """The data-parallel wrapper's reducer when it runs in mode "zero1" and the last backward left this rank with shards to step."""
+        ddp = getattr(self._fused["model"], "_ddp", None) if self._fused else None
+        red = getattr(ddp, "reducer", None)
+        if red is None or red.mode != "zero1" or not (red.sharded or red.replicated):
+            return None
+        return red
+
+    def _step_zero1(self, a, arena, red):
+        """Sharded step (volta_amd/parallel.py, mode "zero1"): the fused kernel runs over the element ranges this rank owns -- its 1/world
+        shard of every bucket plus the few replicated slots -- then the updated master weights are all-gathered and the bf16 copies re-cast.
+        The moments of foreign shards are left alone; should the shard layout change (another batch shape compiles another bucket plan),
+        they are gathered under the old layout first."""
+        f = self._fused
+        layout = tuple(red.sharded)
+        prev = f.get("zero1_layout")
+        if prev is not None and prev != layout:
+            red.gather(f["m"], prev)
+            red.gather(f["v"], prev)
+        f["zero1_layout"] = layout
+        base = (a.p, a.g, a.m, a.v, a.shadow, a.chunk_class)
+        for lo, hi in red.owned():
+            assert lo % 1024 == 0 and hi % 1024 == 0 and hi > lo, (lo, hi)
+            a.p, a.g, a.m, a.v = base[0] + 4 * lo, base[1] + 4 * lo, base[2] + 4 * lo, base[3] + 4 * lo
+            a.shadow, a.chunk_class = base[4] + 2 * lo, base[5] + lo // 1024
+            a.n = hi - lo
+            L.check(L.lib.vk_adamw_step(C.byref(a), L.stream_ptr()))
+        f["model"]._ddp.gather_params(arena)
 
     def _step_pipelined(self, a, arena, clip):
         f = self._fused
@@ -209,6 +241,10 @@ class AdamW(Optimizer):
 
     def state_dict(self):
         self.synchronize()
+        red = self._zero1_reducer()
+        if red is not None and self._fused.get("zero1_layout"):       # every rank's checkpoint holds the whole state
+            red.gather(self._fused["m"], self._fused["zero1_layout"])
+            red.gather(self._fused["v"], self._fused["zero1_layout"])
         sd = super().state_dict()
         if self._fused is not None and self._fused["step"] > 0:
             f = self._fused
@@ -306,10 +342,24 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, defer_to_optimizer=Fals
                 cc[c0:c1] = 0
             cache[key] = cc.to(arena.device)
         mask = cache[key]
-    if not hasattr(arena, "norm_ws"):
-        arena.norm_ws = torch.empty(L.lib.vk_grad_norm_workspace_floats(), device=arena.device)
+    # per-slot sums of squares, then one fixed-order sum: a function of the gradient values alone, so a rank that owns only part of the
+    # arena (data-parallel mode "zero1") and receives the other ranks' slot sums obtains the same bits as one that holds everything
+    nchunks = arena.total // 1024
+    if not hasattr(arena, "norm_chunks"):
+        arena.norm_chunks = torch.zeros(nchunks, device=arena.device)
+    sums = arena.norm_chunks
     out = torch.empty(2, device=arena.device)
-    L.check(L.lib.vk_grad_norm_clip_masked(L.ptr(arena.grad), arena.total, L.ptr(mask), pre_scale, float(max_norm), L.ptr(arena.norm_ws), L.ptr(out), L.stream_ptr()))
+    ddp = getattr(model, "_ddp", None)
+    red = getattr(ddp, "reducer", None)
+    if red is not None and red.mode == "zero1" and (red.sharded or red.replicated):
+        sums.zero_()
+        mine = [(lo + red.rank * s, lo + (red.rank + 1) * s) for lo, hi, s in red.sharded] + (list(red.replicated) if red.rank == 0 else [])
+        for lo, hi in mine:
+            L.check(L.lib.vk_grad_sqnorm_chunks(L.ptr(arena.grad), lo // 1024, (hi - lo) // 1024, L.ptr(mask), L.ptr(sums), L.stream_ptr()))
+        torch.distributed.all_reduce(sums, group=red.pg)        # every slot has one contributor: the sum adds zeros, exactly
+    else:
+        L.check(L.lib.vk_grad_sqnorm_chunks(L.ptr(arena.grad), 0, nchunks, L.ptr(mask), L.ptr(sums), L.stream_ptr()))
+    L.check(L.lib.vk_grad_norm_from_chunks(L.ptr(sums), nchunks, pre_scale, float(max_norm), L.ptr(out), L.stream_ptr()))
     if defer_to_optimizer:
         arena.pending_clip = out
     elif mask is None:
