@@ -401,7 +401,8 @@ int vk_grad_norm_clip_masked(const float* g, int64_t n, const uint8_t* chunk_cla
  * fixed order (double) and leaves out[0..1] as vk_grad_norm_clip does.  A rank that computed only its own chunks and received the other
  * ranks' sums obtains exactly the bits of a rank that computed them all. */
 int vk_grad_sqnorm_chunks(const float* g, int64_t chunk0, int64_t nchunks, const uint8_t* chunk_class, float* sums, vk_stream_t s);
-int vk_grad_norm_from_chunks(const float* sums, int64_t total_chunks, float pre_scale, float max_norm, float* out, vk_stream_t s);
+/* `sums`: total_chunks floats (total_chunks even, buffer 8-byte aligned) followed by 256 floats of scratch for the first level of the sum. */
+int vk_grad_norm_from_chunks(float* sums, int64_t total_chunks, float pre_scale, float max_norm, float* out, vk_stream_t s);
 typedef struct vk_adamw_args {
     float* p;
     const float* g;

@@ -42,6 +42,16 @@ def test_gated_attention_other_head_sizes(gname, T, R, nh, dh, train):
     _run(gname, T, R, train, nh, dh)
 
 
+@pytest.mark.parametrize("gname", list(GATES))
+@pytest.mark.parametrize("T,R,nh,dh", [(80, 37, 12, 64), (20, 201, 12, 64), (30, 307, 12, 64), (38, 257, 12, 64), (40, 201, 8, 128)])
+@pytest.mark.parametrize("train", [False, True])
+def test_gated_attention_long_rows(gname, T, R, nh, dh, train):
+    """Rows beyond the MFMA kernels' tiles (more than 64 text tokens / 128 regions): the task configs' lengths -- VCR 80 tokens, Visual7W
+    and FlickrGrounding 200 regions (+ global), GuessWhatPointing 256 / 306 (config_tasks/all_tasks.yml:59-70,95-105,306-335) -- on the
+    generic kernels, forward and backward, every gate pattern, with the dropout stream replayed."""
+    _run(gname, T, R, train, nh, dh)
+
+
 def _run(gname, T, R, train, nh, dh):
     from volta_amd import _lib as L_, ops
     from oracle import volta_ref as Rf

@@ -82,13 +82,12 @@ def _worker(rank, world, port, shared_gpu=False):
             if mode == "zero1":
                 assert ddp.reducer.sharded, "no bucket was sharded"
             m2.__dict__["_ddp"] = None
-        # (two ranks: a + b is the same sum in any order, the two paths agree bit for bit; with more ranks the collectives add a slot's
-        # `world` contributions in different ring orders -- last-bit differences of the averaged gradient, hence a tolerance)
+        # (between the two RUNS a last-bit tolerance: the backward's embedding and loss row sums are accumulated with float atomics, so
+        # two backward passes over the same batch already differ in the last bit (tests/test_fullsize_gpu.py), and with more than two
+        # ranks the collectives add a slot's contributions in different ring orders.  Within a run the replicas are bit-identical.)
         for a, b2, what in zip(runs["allreduce"][:4], runs["zero1"][:4], ("master weights", "bf16 copies", "exp_avg", "exp_avg_sq")):
-            if world == 2:
-                assert torch.equal(a, b2), "zero1 vs unsharded: %s differ (max %g)" % (what, float((a.float() - b2.float()).abs().max()))
-            else:
-                assert float((a.float() - b2.float()).norm() / b2.float().norm()) <= 1e-5, what
+            err = float((a.float() - b2.float()).norm() / b2.float().norm())
+            assert err <= 1e-6, "zero1 vs unsharded: %s differ by %g" % (what, err)
         mine = runs["zero1"][0]
         other = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(other, mine)

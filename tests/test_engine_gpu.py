@@ -62,8 +62,19 @@ def test_forward_backward_parity_other_lengths(T, Rn):
     _parity("vilbert", True, 4, T, Rn, batch_seed=9)      # (seed 7 leaves the (64, 127) batch without a single labelled row)
 
 
-def _parity(name, train, B, T, Rn, batch_seed=7):
+@pytest.mark.parametrize("T,Rn,seed", [(80, 36, 5), (20, 200, 3), (30, 306, 4)])      # (seeds that leave B = 2 with labelled rows)
+def test_forward_backward_parity_long_rows(T, Rn, seed):
+    """The reference's task lengths beyond the MFMA attention tiles (VCR max_seq_length 80, Visual7W / FlickrGrounding max_region_num 200,
+    GuessWhatPointing 306: config_tasks/all_tasks.yml:59-70,95-105,306-335) end to end on the engine: generic attention kernels, every
+    other launch unchanged."""
+    _parity("vilbert", True, 2, T, Rn, batch_seed=seed, max_pos=128)
+
+
+def _parity(name, train, B, T, Rn, batch_seed=7, max_pos=None):
     from oracle import volta_ref as R
+    if max_pos is not None:
+        CONFIGS["_long"] = dict(CONFIGS[name], max_position_embeddings=max_pos)
+        name = "_long"
     model, rcfg, sd = build(name)
     batch = R.synthetic_batch(rcfg, B, T, Rn, seed=batch_seed, pad=True)
     seed = 0xABCDEF12345

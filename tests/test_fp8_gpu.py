@@ -133,9 +133,14 @@ def test_gemm_fp8_gelu_group_and_dyn_rows():
 
 
 # ---------------------------------------------------------------------------------------------------- the engine with fp8 projections
+# Gates = at most 2 x the values observed on MI355X (round 3, gpurun_out -> profiles/r03_fp8_observed.txt):
+#   reduced-depth models   hidden 0.090 / 0.076 / 0.067, MLM loss 3.2e-3 / 3.1e-3 / 2.8e-3, region loss 7.8e-3 / 2.3e-3 / 1.1e-3,
+#                          smallest gradient cosine 0.964 / 0.989 / 0.987   (vilbert / uniter / vlbert)
+#   ctrl_vl-bert_base, 100 regions, real-reference fixture   MLM 1.0e-3, region 2.3e-3, ITM 2.5e-2 (B = 2), hidden states 0.107
 FP8_HIDDEN_TOL = 0.15       # relative L2 of hidden states after 4-8 sub-layers: every e4m3 product carries ~5 % relative noise (3 mantissa bits on both
-                            # operands, independent per term), which LayerNorm and the residual stream pass on; observed 0.05-0.09
-FP8_LOSS_TOL = 2e-2         # relative, MLM / region losses
+                            # operands, independent per term), which LayerNorm and the residual stream pass on; observed <= 0.090
+FP8_LOSS_TOL = 6.5e-3       # relative, MLM loss; observed <= 3.2e-3
+FP8_IMG_LOSS_TOL = 1.6e-2   # relative, region loss; observed <= 7.8e-3
 
 
 @pytest.mark.parametrize("name", ["vilbert", "uniter", "vlbert"])
@@ -179,8 +184,8 @@ def test_engine_fp8_forward_backward_against_oracle(name):
         cos.append(float((gg * leaf.grad).sum() / (gg.norm() * leaf.grad.norm())))
     report["min_grad_cos"] = min(cos)
     print(name, {k: float("%.3g" % v) for k, v in report.items()})
-    assert report["hidden"] <= FP8_HIDDEN_TOL and report["lm"] <= FP8_LOSS_TOL and report["img"] <= FP8_LOSS_TOL, report
-    assert report["min_grad_cos"] >= 0.95, report          # straight-through backward over the noisy forward activations; observed >= 0.965
+    assert report["hidden"] <= FP8_HIDDEN_TOL and report["lm"] <= FP8_LOSS_TOL and report["img"] <= FP8_IMG_LOSS_TOL, report
+    assert report["min_grad_cos"] >= 0.95, report          # straight-through backward over the noisy forward activations; observed >= 0.964 (1 - cos <= 1.4 x observed)
 
 
 def test_ctrl_vlbert_100_regions_fp8_against_reference_fixture(golden_dir):
@@ -214,8 +219,8 @@ def test_ctrl_vlbert_100_regions_fp8_against_reference_fixture(golden_dir):
     ref = z["out::seq_t_slice"]
     report["seq_t"] = float(np.linalg.norm(seq_t[:, :, :64] - ref) / np.linalg.norm(ref))
     print(name, "fp8", {k: float("%.3g" % v) for k, v in report.items()})
-    assert report["loss_lm"] <= FP8_LOSS_TOL and report["loss_img"] <= FP8_LOSS_TOL and report["loss_nsp"] <= 0.1, report       # ITM: 2 samples
-    assert report["seq_t"] <= 0.15, report          # 24 sub-layers of fp8 projections
+    assert report["loss_lm"] <= 2.1e-3 and report["loss_img"] <= 4.5e-3 and report["loss_nsp"] <= 5.1e-2, report       # observed 1.0e-3 / 2.3e-3 / 2.5e-2 (ITM: 2 samples)
+    assert report["seq_t"] <= 0.15, report          # 24 sub-layers of fp8 projections; observed 0.107
 
 
 def test_ln_fwd_writes_row_quantised_copy():

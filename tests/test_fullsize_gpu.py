@@ -41,8 +41,8 @@ def test_full_size_batch_properties(name, B):
     b = synthetic_batch(cfg, B, 20, 36, seed=1234, device="cuda")
     full, g_full, n_full = _run(model, b)
     again, g_again, _ = _run(model, b)
-    for a, c in zip(full, again):                                   # same inputs, same losses (row sums are atomically accumulated: last-bit order effects)
-        assert abs(a - c) <= 1e-6 * abs(a), (full, again)
+    for a, c in zip(full, again):                                   # same inputs, same losses (row sums are atomically accumulated: last-bit order effects,
+        assert abs(a - c) <= 5e-6 * abs(a), (full, again)           # up to ~10 ulp observed over ctrl_lxmert's four visual losses)
     assert float((g_full - g_again).abs().max()) <= 1e-6 * float(g_full.abs().max()) + 1e-9      # (embedding rows: atomics)
     # ---- permutation of the pairs
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(3)).cuda()

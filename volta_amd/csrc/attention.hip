@@ -552,7 +552,8 @@ static bool bwd_fits(int TP, int RP, int dht) { return 4 * (TP + RP) * 2 * dht +
 namespace vk { int attn_generic(const vk_attn_args* a, const vk_attn_bwd_args* bw, vk_stream_t stream); }      // attention_generic.hip
 
 // Head sizes: 64 (every ctrl_* config) and 128 (config/vilbert_base.json) run on the MFMA kernels above; 128 with the longest sequences
-// (more than 96 padded rows: the backward's images exceed the LDS) and the other sizes (32, 96) on the generic kernels.
+// (more than 96 padded rows: the backward's images exceed the LDS), the other sizes (32, 96) and every head size with rows beyond the
+// MFMA tiles (more than 64 text tokens or 128 regions: the task configs of config_tasks/all_tasks.yml) on the generic kernels.
 #ifdef VK_STUDY
 static int g_attn_force_generic = 0;      // A/B hook: 128-wide heads on the generic kernels
 extern "C" void vk_attn_set_force_generic(int v) { g_attn_force_generic = v; }
@@ -560,6 +561,10 @@ extern "C" void vk_attn_set_force_generic(int v) { g_attn_force_generic = v; }
 static constexpr int g_attn_force_generic = 0;
 #endif
 static bool attn_mfma_ok(const vk_attn_args* a) {
+    for (int m = 0; m < 2; ++m) {             // rows beyond the MFMA kernels' tiles (64 text tokens, 128 regions): the generic kernels, at any head size
+        const bool on = a->gate[m][0] || a->gate[m][1] || a->gate[0][m] || a->gate[1][m];
+        if (on && a->L[m] > (m == 0 ? 64 : 128)) return false;
+    }
     if (a->dh == 0 || a->dh == 64) return true;
     if (a->dh != 128 || g_attn_force_generic) return false;
     const int TP = a->L[0] > 32 ? 64 : 32, RP = a->L[1] > 64 ? 128 : 64;

@@ -62,17 +62,23 @@ __global__ __launch_bounds__(256) void sqnorm_chunks_kernel(const float* g, size
     s = wave_sum(s);
     if (lane == 0) sums[chunk] = s;
 }
-__global__ __launch_bounds__(1024) void sqnorm_from_chunks_kernel(const float* sums, size_t n, float pre_scale, float max_norm, float* out) {
-    __shared__ double sh[16];
+// fixed-order sum of the chunk sums in two levels: SQ_GROUPS workgroups add contiguous runs in double, one workgroup adds their results
+constexpr int SQ_GROUPS = 128;
+__global__ __launch_bounds__(256) void sqnorm_groups_kernel(const float* sums, size_t n, double* group) {
+    __shared__ double sh[4];
+    const size_t per = (n + SQ_GROUPS - 1) / SQ_GROUPS, lo = (size_t)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
     double s = 0.0;
-    for (size_t i = threadIdx.x; i < n; i += 1024) s += (double)sums[i];
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) s += (double)sums[i];
     for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
     __syncthreads();
+    if (threadIdx.x == 0) group[blockIdx.x] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(64) void sqnorm_from_groups_kernel(const double* group, float pre_scale, float max_norm, float* out) {
+    double s = group[threadIdx.x] + group[threadIdx.x + 64];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
     if (threadIdx.x == 0) {
-        double t = 0.0;
-        for (int i = 0; i < 16; ++i) t += sh[i];
-        const float norm = (float)sqrt(t) * pre_scale;
+        const float norm = (float)sqrt(s) * pre_scale;
         out[0] = norm;
         float coef = 1.f;
         if (max_norm > 0.f) { coef = max_norm / (norm + 1e-6f); if (coef > 1.f) coef = 1.f; }
@@ -263,9 +269,12 @@ extern "C" int vk_grad_sqnorm_chunks(const float* g, int64_t chunk0, int64_t nch
     return check_launch("vk_grad_sqnorm_chunks");
 }
 
-extern "C" int vk_grad_norm_from_chunks(const float* sums, int64_t total_chunks, float pre_scale, float max_norm, float* out, vk_stream_t s) {
+extern "C" int vk_grad_norm_from_chunks(float* sums, int64_t total_chunks, float pre_scale, float max_norm, float* out, vk_stream_t s) {
     if (total_chunks <= 0) return set_error("vk_grad_norm_from_chunks: no chunks");
-    hipLaunchKernelGGL(sqnorm_from_chunks_kernel, dim3(1), dim3(1024), 0, (hipStream_t)s, sums, (size_t)total_chunks, pre_scale, max_norm, out);
+    if (((uintptr_t)(sums + total_chunks)) & 7) return set_error("vk_grad_norm_from_chunks: total_chunks must be even (the group sums follow the chunk sums as doubles)");
+    double* group = (double*)(sums + total_chunks);           // 128 doubles behind the chunk sums (see the header)
+    hipLaunchKernelGGL(sqnorm_groups_kernel, dim3(SQ_GROUPS), dim3(256), 0, (hipStream_t)s, sums, (size_t)total_chunks, group);
+    hipLaunchKernelGGL(sqnorm_from_groups_kernel, dim3(1), dim3(64), 0, (hipStream_t)s, (const double*)group, pre_scale, max_norm, out);
     return check_launch("vk_grad_norm_from_chunks");
 }
 

@@ -264,8 +264,10 @@ class StepEngine:
         if cfg.fusion_method not in ("mul", "sum", "text", "vl-bert_vqa", "none"):
             raise ValueError("Invalid fusion method: %s" % cfg.fusion_method)
         self.unused_params = set()    # parameters no launch of this plan reads: their .grad stays None, as under the reference's autograd
-        if T > 64 or Rv > 128:
-            raise NotImplementedError("sequence lengths above (64, 128) exceed the attention tile budget")
+        # rows beyond the MFMA attention tiles (64 text tokens, 128 regions: VCR's 80-token captions, 200 / 256 / 306 regions of the
+        # grounding tasks, config_tasks/all_tasks.yml) run on the generic attention kernels: up to 512 keys per query row
+        if T + Rv > 512:
+            raise NotImplementedError("more than 512 keys per query row (%d text + %d vision rows)" % (T, Rv))
         self.H, self.I, self.nh = H, cfg.intermediate_size, cfg.num_attention_heads
         self.st = [Stream(T, B, H), Stream(Rv, B, Hv)]
         self.R = Rv - (1 if cfg.add_global_imgfeat is not None else 0)

@@ -345,9 +345,10 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, defer_to_optimizer=Fals
     # per-slot sums of squares, then one fixed-order sum: a function of the gradient values alone, so a rank that owns only part of the
     # arena (data-parallel mode "zero1") and receives the other ranks' slot sums obtains the same bits as one that holds everything
     nchunks = arena.total // 1024
+    npad = nchunks + (nchunks & 1)                     # an even count: the first-level sums follow the slot sums as doubles
     if not hasattr(arena, "norm_chunks"):
-        arena.norm_chunks = torch.zeros(nchunks, device=arena.device)
-    sums = arena.norm_chunks
+        arena.norm_chunks = torch.zeros(npad + 256, device=arena.device)
+    sums = arena.norm_chunks[:npad]
     out = torch.empty(2, device=arena.device)
     ddp = getattr(model, "_ddp", None)
     red = getattr(ddp, "reducer", None)
@@ -359,7 +360,7 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, defer_to_optimizer=Fals
         torch.distributed.all_reduce(sums, group=red.pg)        # every slot has one contributor: the sum adds zeros, exactly
     else:
         L.check(L.lib.vk_grad_sqnorm_chunks(L.ptr(arena.grad), 0, nchunks, L.ptr(mask), L.ptr(sums), L.stream_ptr()))
-    L.check(L.lib.vk_grad_norm_from_chunks(L.ptr(sums), nchunks, pre_scale, float(max_norm), L.ptr(out), L.stream_ptr()))
+    L.check(L.lib.vk_grad_norm_from_chunks(L.ptr(sums), npad, pre_scale, float(max_norm), L.ptr(out), L.stream_ptr()))
     if defer_to_optimizer:
         arena.pending_clip = out
     elif mask is None:
