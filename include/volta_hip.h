@@ -91,7 +91,7 @@ int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* probs, int 
 /* Same with the tile geometry chosen by the caller instead of the shape heuristic (0 = heuristic): 128 (128 x 128 tiles, 4 waves),
  * 258 / 259 / 260 (256 x 256 / 192 / 128 tiles, 8 waves, LDS-DMA ring), optionally OR-ed with VK_GEMM_PERSISTENT (one workgroup per CU
  * walks the tile list; NT / NN without `dyn`) or VK_GEMM_ONE_TILE_PER_WG; 261 (256 x 128 tiles, 4 waves, 72 KiB of LDS: two
- * workgroups per CU, csrc/gemm4w.hip).  A per-call argument, no library state: re-entrant. */
+ * workgroups per CU, csrc/gemm4w.hip); 262 (128 x 128 tiles, 4 waves, ring of 6 K-steps: launches too small for 256-row tiles).  A per-call argument, no library state: re-entrant. */
 #define VK_GEMM_PERSISTENT 0x1000
 #define VK_GEMM_ONE_TILE_PER_WG 0x2000
 int vk_gemm_grouped_ex(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, int geometry, vk_stream_t s);

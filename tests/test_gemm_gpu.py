@@ -10,7 +10,7 @@ def _mods():
     return L, ops
 
 
-GEOMETRIES = {"auto": 0, "tile128x128": 128, "tile256x256": 258, "tile256x192": 259, "tile256x128": 260, "tile256x128_4wave": 261,
+GEOMETRIES = {"auto": 0, "tile128x128": 128, "tile256x256": 258, "tile256x192": 259, "tile256x128": 260, "tile256x128_4wave": 261, "tile128x128_4wave_ring": 262,
               "tile256x256_persistent": 258 | 0x1000, "tile256x192_persistent": 259 | 0x1000}
 
 

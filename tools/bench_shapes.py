@@ -12,6 +12,10 @@ SHAPES = [  # name, layout, epilogue, [(M, N, K), ...]
     ("text out fwd", L.NT, L.EPI_BF16, [(5120, 768, 768)]),
     ("text ffn-up gelu", L.NT, L.EPI_GELU, [(5120, 3072, 768)]),
     ("text ffn-down", L.NT, L.EPI_BF16, [(5120, 768, 3072)]),
+    ("text ffn-down dgrad mulr", L.NN, L.EPI_MULR, [(5120, 3072, 768)]),
+    ("text ffn-up dgrad addr", L.NN, L.EPI_ADDR, [(5120, 768, 3072)]),
+    ("text out dgrad", L.NN, L.EPI_BF16, [(5120, 768, 768)]),
+    ("text qkv dgrad addr", L.NN, L.EPI_ADDR, [(5120, 768, 2304)]),
     ("dual qkv fwd", L.NT, L.EPI_BF16, [(5120, 2304, 768), (9472, 2304, 768)]),
     ("dual out fwd", L.NT, L.EPI_BF16, [(5120, 768, 768), (9472, 768, 768)]),
     ("dual ffn-up gelu", L.NT, L.EPI_GELU, [(5120, 3072, 768), (9472, 3072, 768)]),

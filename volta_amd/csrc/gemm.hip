@@ -305,16 +305,24 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
             edge = c192 < 0.97 * c256 ? 259 : 258;
         }
     }
-    if (edge == 256 || edge == 258 || edge == 259 || edge == 260 || edge == 261) {
+    if (edge == 128 && (geometry & 0xFFF) == 0 && layout == VK_NT && !any_dyn) {
+        // launches too small for 256-row tiles, K-contiguous operands: the 4-wave ring kernel with 128 x 128 tiles (five K-steps in flight,
+        // one workgroup per CU) instead of the double-buffered one -- text-only FFN-down 56.5 -> 48.1 us, attention output 22.0 -> 19.0
+        // (profiles/r03_gemm_shapes.txt); the transposed-operand layouts measured no better on it
+        bool deep = true;
+        for (int i = 0; i < nprob; ++i) deep &= probs[i].M >= 1024 && probs[i].K >= 512;
+        if (deep) edge = 262;
+    }
+    if (edge == 256 || edge == 258 || edge == 259 || edge == 260 || edge == 261 || edge == 262) {
         for (int i = 0; i < nprob; ++i) {
             const vk_gemm_problem& q = probs[i];
             const uint64_t ea = (uint64_t)(layout == VK_TN ? q.K : q.M) * q.lda * 2, eb = (uint64_t)(layout == VK_NT ? q.N : q.K) * q.ldb * 2;
             if (ea >= 0x7FFFFFF0ull || eb >= 0x7FFFFFF0ull) { edge = 128; break; }     // the LDS-DMA kernels address operands below 2 GiB
         }
     }
-    if (edge != 256 && edge != 258 && edge != 259 && edge != 260 && edge != 261) edge = 128;
+    if (edge != 256 && edge != 258 && edge != 259 && edge != 260 && edge != 261 && edge != 262) edge = 128;
     if (any_split && edge != 258 && edge != 259) return set_error("vk_gemm_grouped: split accumulation runs on the 256 x 256 / 256 x 192 geometries (258 / 259), got %d", geometry & 0xFFF);
-    const int bm = edge == 128 ? 128 : 256, bn = edge == 259 ? 192 : (edge == 260 || edge == 261) ? 128 : bm;
+    const int bm = (edge == 128 || edge == 262) ? 128 : 256, bn = edge == 259 ? 192 : (edge == 260 || edge == 261 || edge == 262) ? 128 : bm;
     KGroup g;
     g.nprob = nprob;
     g.stagger = (g_stagger & 0xFF) | ((g_debug & 0xFF) << 8);
@@ -336,7 +344,7 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
     }
     if (total == 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (edge == 261) return launch_gemm4w(layout, epilogue, g, total, s);      // half-CU tiles: two workgroups per CU
+    if (edge == 261 || edge == 262) return launch_gemm4w(layout, epilogue, g, total, s, edge == 262 ? 128 : 256);      // 4-wave ring kernels
     if (edge == 256 || edge == 258 || edge == 259 || edge == 260) {
         // more than one round of tiles: one workgroup per CU walks the list (gemm256p_kernel); device-side row counts keep the
         // one-tile-per-workgroup launch (dead tiles exit at once there)

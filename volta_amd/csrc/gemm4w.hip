@@ -14,19 +14,23 @@
 // WAR: the slot of K-step p - 1 was last read in phase p - 1, those reads retired (lgkmcnt(0)) before that phase's MFMAs and every wave
 // has passed that phase's barrier.  RAW: every wave's vmcnt(6) of phase p precedes the barrier of phase p, K-step p + 1 is first read in
 // phase p + 1.  The matrix pipe of a SIMD is kept busy across a wave's read / wait bubble by the co-resident workgroup's wave.
+//
+// The same loop with 64-row wave tiles (TI = 4: a 128 x 128 workgroup tile, 16 KiB per K-step) and a ring of 6 K-steps serves the launches
+// that cannot fill the chip with 256-row tiles and are deep in K (the text-only sub-layers' [5120 x 768 x 3072]: 80 tiles of 256 x 192,
+// 240 of 128 x 128): one workgroup per CU, five K-steps in flight in front of the one being read.
 #include "gemm_common.h"
 
 namespace vk {
 
-constexpr uint32_t W4_SLOT = 24576, W4_A = 16384;
 constexpr uint32_t W4_OOB = 0x80000000u;
 
 __device__ __forceinline__ int kswz4(int r) { return (-(r >> 2)) & 3; }
 
 // byte offsets (K-step 0) of the 16-byte pieces a thread stages of a strip of EXT rows (K-contiguous: image [EXT][32 k], 64-byte rows,
 // chunk c of row r at chunk c ^ kswz4(r)) or EXT columns (transposed: image [32 k][EXT], 2 EXT-byte rows, chunk XOR tswz(k row))
-template <bool T, int EXT>
-__device__ __forceinline__ void strip_offsets4(uint32_t (&off)[EXT / 64], int ld, int ext0, int tid) {
+template <bool T, int EXT, int NMAX>
+__device__ __forceinline__ void strip_offsets4(uint32_t (&off)[NMAX], int ld, int ext0, int tid) {
+    static_assert(EXT / 64 <= NMAX, "offset array too small");
 #pragma unroll
     for (int i = 0; i < EXT / 64; ++i) {
         const int lin = i * 256 + tid;
@@ -54,9 +58,19 @@ __device__ __forceinline__ bf16x8 frag_strip4(uint32_t strip, int r0, int lane) 
         __builtin_amdgcn_sched_barrier(0);        \
     } while (0)
 
-template <bool AT, bool BT, int EPI>
-__global__ __launch_bounds__(256, 2) void gemm4w_kernel(const KGroup g) {
+// TI: 16-row tiles per wave along M (8: 256-row workgroup tile, 4: 128); RING: K-steps of LDS.  (The derived constants live in a class
+// template: taken from local constexpr variables as array bounds / template arguments they made hipcc drop the kernel without a diagnostic.)
+template <int TI, int RING> struct W4Geo {
+    static constexpr int BM = 32 * TI, NPA = BM / 64, NPW = NPA + 2, PF = RING - 1;       // DMA pieces per wave and K-step: A, A + B; K-steps staged ahead
+    static constexpr uint32_t A_BYTES = (uint32_t)BM * 64u, SLOT = A_BYTES + 8192u;
+};
+
+template <bool AT, bool BT, int EPI, int TI, int RING>
+__global__ __launch_bounds__(256, TI == 8 ? 2 : 1) void gemm4w_kernel(const KGroup g) {
     constexpr bool BG = AT && BT;
+    using G = W4Geo<TI, RING>;
+    constexpr int BM = G::BM, NPA = G::NPA, NPW = G::NPW, PF = G::PF;
+    constexpr uint32_t A_BYTES = G::A_BYTES, SLOT = G::SLOT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(VK_LDS char*)smem;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -71,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(const KGroup g) {
     const KProb& P = g.p[pi];
     const int t = bid - P.tile_start;
     const int tm = t / P.tiles_n, tn = t - tm * P.tiles_n;
-    const int m0 = tm * 256, n0 = tn * 128;
+    const int m0 = tm * BM, n0 = tn * 128;
 
     int M = P.M, K = P.K;
     if (P.dyn) {
@@ -85,80 +99,90 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(const KGroup g) {
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(P.A, a_rows > 0 ? (uint32_t)(((uint32_t)(a_rows - 1) * P.lda + a_cols) * 2u) : 0u);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(P.B, b_rows > 0 ? (uint32_t)(((uint32_t)(b_rows - 1) * P.ldb + b_cols) * 2u) : 0u);
 
-    uint32_t offA[4], offB[2];
-    strip_offsets4<AT, 256>(offA, P.lda, m0, tid);
-    strip_offsets4<BT, 128>(offB, P.ldb, n0, tid);
+    uint32_t offA[4], offB[2];            // (fixed bounds: an array whose bound depends on a template parameter, captured by the staging lambda, made hipcc drop the kernel without a diagnostic)
+    strip_offsets4<AT, G::BM, 4>(offA, P.lda, m0, tid);
+    strip_offsets4<BT, 128, 2>(offB, P.ldb, n0, tid);
     // (columns of a transposed strip beyond the operand's extent read whatever follows in memory: they only reach output rows / columns
     // that the epilogue never stores; reads past the end of the buffer return zero)
     const uint32_t kA = AT ? 64u * (uint32_t)P.lda : 64u, kB = BT ? 64u * (uint32_t)P.ldb : 64u;     // bytes per 32-deep K-step
     const int np = (K + 31) / 32;
     auto stage = [&](int p, int slot) {
         const bool live = p < np;
-        const uint32_t sa = lds0 + (uint32_t)slot * W4_SLOT;
+        const uint32_t sa = lds0 + (uint32_t)slot * SLOT;
         const uint32_t addA = live ? (uint32_t)p * kA : W4_OOB, addB = live ? (uint32_t)p * kB : W4_OOB;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < NPA; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (VK_LDS void*)(uintptr_t)(sa + (uint32_t)(i * 256 + wave * 64) * 16u), 16, offA[i] + addA, 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (VK_LDS void*)(uintptr_t)(sa + W4_A + (uint32_t)(i * 256 + wave * 64) * 16u), 16, offB[i] + addB, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (VK_LDS void*)(uintptr_t)(sa + A_BYTES + (uint32_t)(i * 256 + wave * 64) * 16u), 16, offB[i] + addB, 0, 0, 0);
     };
 
-    f32x4 acc[8][4];
+    f32x4 acc[TI][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < TI; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 accb[8];
+    f32x4 accb[TI];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < TI; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     const bool do_bias_grad = BG && (P.bias_grad != nullptr) && (tn == 0) && (wc == 0);
     bf16x8 ones;
 #pragma unroll
     for (int i = 0; i < 8; ++i) ones[i] = (short)0x3F80;
 
-    stage(0, 0); stage(1, 1);
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    // vmcnt(NPW * (PF - 1)): of the PF K-steps staged ahead all but the oldest may still be in flight
+    static_assert(NPW * (PF - 1) == 6 || NPW * (PF - 1) == 16, "add the wait count of this geometry");
+#define W4_WAIT_STAGE()                                                               \
+    do {                                                                              \
+        if constexpr (NPW * (PF - 1) == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  \
+        else asm volatile("s_waitcnt vmcnt(16)" ::: "memory");                        \
+    } while (0)
+#pragma unroll
+    for (int i = 0; i < PF; ++i) stage(i, i);
+    W4_WAIT_STAGE();
     W4_BARRIER();
-    int rd = 0, wrs = 2;
+    int rd = 0, wrs = PF;
     for (int p = 0; p < np; ++p) {
-        const uint32_t sa = lds0 + (uint32_t)rd * W4_SLOT, sb = sa + W4_A;
-        bf16x8 a[8], b[4];
+        const uint32_t sa = lds0 + (uint32_t)rd * SLOT, sb = sa + A_BYTES;
+        bf16x8 a[TI], b[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) b[j] = BT ? frag_cols<256>(sb, wc * 64 + j * 16, 0, lane) : frag_strip4(sb, wc * 64 + j * 16, lane);
 #pragma unroll
-        for (int i = 0; i < 8; ++i) a[i] = AT ? frag_cols<512>(sa, wr * 128 + i * 16, 0, lane) : frag_strip4(sa, wr * 128 + i * 16, lane);
-        stage(p + 2, wrs);
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        for (int i = 0; i < TI; ++i) a[i] = AT ? frag_cols<2 * G::BM>(sa, wr * (BM / 2) + i * 16, 0, lane) : frag_strip4(sa, wr * (BM / 2) + i * 16, lane);
+        stage(p + PF, wrs);
+        W4_WAIT_STAGE();
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 0; i < TI; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[j], a[i], acc[i][j], 0, 0, 0);
         if (BG && do_bias_grad) {
 #pragma unroll
-            for (int i = 0; i < 8; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i], accb[i], 0, 0, 0);
+            for (int i = 0; i < TI; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, a[i], accb[i], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
         W4_BARRIER();
-        rd = rd == 2 ? 0 : rd + 1;
-        wrs = wrs == 2 ? 0 : wrs + 1;
+        rd = rd == RING - 1 ? 0 : rd + 1;
+        wrs = wrs == RING - 1 ? 0 : wrs + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // retire the zero-fill stages issued past the end of K
     W4_BARRIER();                                          // ... of every wave: the ring is free for the epilogue's transposition
 
-    gemm_epilogue<AT, EPI, 8, 4>(P, acc, accb, do_bias_grad, m0 + wr * 128, n0 + wc * 64, M, lane, lds0 + (uint32_t)wave * 16384u);
+#undef W4_WAIT_STAGE
+    gemm_epilogue<AT, EPI, TI, 4>(P, acc, accb, do_bias_grad, m0 + wr * (BM / 2), n0 + wc * 64, M, lane, lds0 + (uint32_t)wave * 16384u);
 }
 
-template <bool AT, bool BT>
+template <bool AT, bool BT, int TI, int RING>
 static int launch_layout4(int epi, const KGroup& g, int total, hipStream_t s) {
-    constexpr int LDS = 3 * W4_SLOT;
+    constexpr int LDS = RING * (32 * TI * 64 + 8192);
+    static_assert(LDS >= 4 * 16384, "the epilogue stages 16 KiB per wave in the ring");
 #define VK_CASE(E)                                                                                        \
     case E: {                                                                                             \
-        auto k = gemm4w_kernel<AT, BT, E>;                                                                \
+        auto k = gemm4w_kernel<AT, BT, E, TI, RING>;                                                      \
         static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); (void)attr; \
         hipLaunchKernelGGL(k, dim3(total), dim3(256), LDS, s, g);                                         \
         break;                                                                                            \
@@ -171,10 +195,16 @@ static int launch_layout4(int epi, const KGroup& g, int total, hipStream_t s) {
     return check_launch("vk_gemm_grouped");
 }
 
-int launch_gemm4w(int layout, int epilogue, const KGroup& g, int total, hipStream_t s) {
-    if (layout == VK_NT) return launch_layout4<false, false>(epilogue, g, total, s);
-    if (layout == VK_NN) return launch_layout4<false, true>(epilogue, g, total, s);
-    if (layout == VK_TN) return launch_layout4<true, true>(epilogue, g, total, s);
+int launch_gemm4w(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int bm) {
+    if (bm == 128) {         // 128 x 128 tiles, ring of 6: one workgroup per CU with five K-steps in flight
+        if (layout == VK_NT) return launch_layout4<false, false, 4, 6>(epilogue, g, total, s);
+        if (layout == VK_NN) return launch_layout4<false, true, 4, 6>(epilogue, g, total, s);
+        if (layout == VK_TN) return launch_layout4<true, true, 4, 6>(epilogue, g, total, s);
+    } else {                 // 256 x 128 tiles, ring of 3: two workgroups per CU
+        if (layout == VK_NT) return launch_layout4<false, false, 8, 3>(epilogue, g, total, s);
+        if (layout == VK_NN) return launch_layout4<false, true, 8, 3>(epilogue, g, total, s);
+        if (layout == VK_TN) return launch_layout4<true, true, 8, 3>(epilogue, g, total, s);
+    }
     return set_error("vk_gemm_grouped: unknown layout %d", layout);
 }
 

@@ -372,7 +372,7 @@ __device__ __forceinline__ bool split_combine(const KProb& P, int tile, f32x4 (&
 // study kernel (VK_STUDY builds only).  persistent: one workgroup per CU walks the tile list (NT / NN, no device-side row counts).
 constexpr int NUM_CU = 256;       // MI355X
 int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant, bool persistent);
-// 256 x 128 tiles, 4 waves, 72 KiB LDS: two workgroups per CU (gemm4w.hip)
-int launch_gemm4w(int layout, int epilogue, const KGroup& g, int total, hipStream_t s);
+// 4-wave ring kernels (gemm4w.hip): bm = 256: 256 x 128 tiles, 72 KiB LDS, two workgroups per CU; bm = 128: 128 x 128 tiles, ring of 6 K-steps
+int launch_gemm4w(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int bm);
 
 }  // namespace vk

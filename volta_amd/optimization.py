@@ -13,6 +13,7 @@ import math
 
 import torch
 import inspect
+import os
 
 from torch.optim import Optimizer
 from torch.optim.lr_scheduler import LambdaLR
