@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from oracle import volta_ref as R  # noqa: E402
 
-POINTS = ("w", "emb", "qkv", "p", "ctx", "d", "z32", "y", "h", "pool")
+POINTS = ("w", "feat", "emb", "qkv", "p", "ctx", "d", "z32", "y", "h", "pool")
 
 
 class Q:
@@ -93,7 +93,10 @@ def forward(sd, cfg, b, on, wfilter=None):
     q = Q(on, wfilter)
     drop = R.Dropper(False)
     t = q(R.emb_text_bert(sd, cfg, b["input_ids"], b["segment_ids"], drop), "emb")
-    v = q(R.emb_image_vilbert(sd, cfg, b["image_feat"], b["image_loc"], drop), "emb")
+    feat = q(b["image_feat"], "feat")               # the engine casts the region features to bf16 for the projection GEMM
+    e = F.linear(feat, q.weight(sd["bert.v_embeddings.image_embeddings.weight"], "bert.v_embeddings.image_embeddings"), sd["bert.v_embeddings.image_embeddings.bias"]) + \
+        F.linear(b["image_loc"], sd["bert.v_embeddings.image_location_embeddings.weight"], sd["bert.v_embeddings.image_location_embeddings.bias"])
+    v = q(R.layer_norm(e, sd["bert.v_embeddings.LayerNorm.weight"], sd["bert.v_embeddings.LayerNorm.bias"]), "emb")
     t_mask = (1.0 - b["input_mask"][:, None, None, :].float()) * -10000.0
     v_mask = (1.0 - b["image_mask"][:, None, None, :].float()) * -10000.0
     for n, typ in R.sublayer_schedule(cfg):

@@ -120,3 +120,40 @@ def test_task_model_trains_with_fused_optimizer():
     assert losses[-1] < losses[0], losses
     for k in ("clfs_dict.TASK1.logit_fc.3.weight", "bert.encoder.layer.0.attention_self.query.weight", "bert.t_pooler.dense.weight"):
         assert not torch.equal(after[k], before[k]), k
+
+
+def test_task_model_dropout_prob_argument():
+    """BertForVLTasks(dropout_prob=...) (encoders.py:1118-1122) sets the dropout on the fused pooled vector: with every other dropout of
+    the configuration at 0, training-mode predictions equal the evaluation ones for dropout_prob = 0, differ for 0.5, and the share of
+    zeroed pooled elements -- read off a linear head on a constant-weight probe -- follows the argument."""
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_engine_gpu import CONFIGS
+    from oracle import volta_ref as R
+    from volta_amd.config import BertConfig
+    from volta_amd.modeling import BertForVLTasks
+    cd = dict(CONFIGS["vilbert"], clf_hidden_size=1536, hidden_dropout_prob=0.0, attention_probs_dropout_prob=0.0,
+              v_hidden_dropout_prob=0.0, v_attention_probs_dropout_prob=0.0)
+    rcfg = R.RefConfig(cd)
+    sd = R.make_task_weights(rcfg, TASK_CFG, ["TASK8"], seed=4, std=0.04)
+    batch = R.synthetic_batch(rcfg, 32, 20, 36, seed=9, pad=True)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    args = (cb["input_ids"], cb["image_feat"], cb["image_loc"], "TASK8", cb["segment_ids"], cb["input_mask"], cb["image_mask"])
+    preds = {}
+    for p_drop in (0.0, 0.1, 0.5):
+        model = BertForVLTasks(BertConfig.from_dict(cd), TASK_CFG, ["TASK8"], dropout_prob=p_drop)
+        model.load_state_dict(sd, strict=True)
+        model = model.cuda()
+        model.eval()
+        with torch.no_grad():
+            ev = model(*args)[0].float().cpu()
+        model.train()
+        model.set_dropout_seed(77)
+        with torch.no_grad():
+            tr = model(*args)[0].float().cpu()
+        preds[p_drop] = (ev, tr)
+    assert torch.allclose(preds[0.0][0], preds[0.0][1], atol=1e-6), "dropout_prob = 0: training mode equals evaluation mode"
+    assert torch.allclose(preds[0.0][0], preds[0.5][0]), "evaluation mode does not depend on dropout_prob"
+    d1 = float((preds[0.1][1] - preds[0.1][0]).abs().mean()), float((preds[0.5][1] - preds[0.5][0]).abs().mean())
+    assert d1[0] > 0 and d1[1] > 1.5 * d1[0], d1            # the perturbation grows with the probability (std ~ sqrt(p / (1 - p)): 3 x from 0.1 to 0.5)
+    with pytest.raises(ValueError):
+        BertForVLTasks(BertConfig.from_dict(cd), TASK_CFG, ["TASK8"], dropout_prob=1.5)

@@ -235,7 +235,7 @@ class StepEngine:
 
     H8_MUL = 8.0           # static scale of the fp8 copy of the GELU output: |h| <= 56 representable, 2^-9 absolute resolution near 0
 
-    def __init__(self, cfg, arena, B, T, Rv, train, heads="pretrain", fp8=False, task=None):
+    def __init__(self, cfg, arena, B, T, Rv, train, heads="pretrain", fp8=False, task=None, task_dropout=0.1):
         """fp8: the forward Q|K|V, FFN-up and FFN-down projections of every sub-layer run on the e4m3 MFMA path (csrc/fp8.hip); inputs are
         quantised per row right before the GEMM, weights per output channel whenever they change; the backward stays bf16.
         heads: "pretrain" = the three pre-training heads and losses (BertForVLPreTraining); "tasks" = poolers only, the
@@ -243,6 +243,7 @@ class StepEngine:
         self.cfg, self.arena, self.B, self.T, self.Rv, self.train = cfg, arena, B, T, Rv, train
         self.heads = heads
         self.task = task              # heads == "tasks": (task id, its task_cfg entry) -- the classifier built behind the poolers
+        self.task_dropout = float(task_dropout)      # BertForVLTasks(dropout_prob=...): nn.Dropout on the fused pooled vector / region states (encoders.py:1118-1122)
         self.fp8 = bool(fp8)
         dev = arena.device
         self.dev = dev
@@ -1456,7 +1457,7 @@ class StepEngine:
 
             if typ.startswith("V-logit"):
                 Mv = st_v.M
-                d0 = self.drop(0.1)                          # BertForVLTasks.dropout on the region states (:1198)
+                d0 = self.drop(self.task_dropout)            # BertForVLTasks.dropout on the region states (:1198)
                 xd = self.buf("task_xd", (Mv, Hv))
                 f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_ADD_DROPOUT, p=(x_v, None, xd), n=(Mv, Hv, 0), f=(1.0,), drop=d0), None, None))
                 if tcfg.get("num_clf_layers", 1) == 2:       # Linear -> GELU -> Dropout -> Linear (:1138-1144)
@@ -1482,7 +1483,7 @@ class StepEngine:
                 if fm == "none":
                     raise ValueError("task type %r needs a pooled output; fusion method 'none' has none (encoders.py:1192-1193)" % typ)
                 fuse = {"mul": L.FUSE_MUL, "sum": L.FUSE_SUM, "text": L.FUSE_TEXT, "vl-bert_vqa": L.FUSE_TEXT}[fm]
-                d0 = self.drop(0.1)                          # BertForVLTasks.dropout on the fused pooled vector (:1184-1191)
+                d0 = self.drop(self.task_dropout)            # BertForVLTasks.dropout on the fused pooled vector (:1184-1191)
                 pooled = self.buf("pooled", (B, P))
                 f.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_POOL_FWD, p=(pt, pv, pooled), n=(B, P, 0, fuse), drop=d0), None, None))
                 rows, K0 = (B // 2, 2 * P) if typ == "VL-binary-classifier" else (B, P)      # NLVR2 pairs: view(-1, 2 P) (:1202)

@@ -301,7 +301,8 @@ class BertForVLPreTraining(PreTrainedModel):
             for k in [k for k in self._engines if k[3] == key[3] and k[5] == task_id]:      # one plan per mode (and task head) keeps memory bounded
                 del self._engines[k]
             task = (task_id, self.task_cfg[task_id]) if task_id is not None else None
-            eng = StepEngine(self.config, arena, B, T, Rv, train, heads=getattr(self, "_heads_mode", "pretrain"), fp8=fp8, task=task)
+            eng = StepEngine(self.config, arena, B, T, Rv, train, heads=getattr(self, "_heads_mode", "pretrain"), fp8=fp8, task=task,
+                             task_dropout=self.__dict__.get("_task_dropout", 0.1))
             self._engines[key] = eng
         return eng
 
@@ -588,8 +589,9 @@ class BertForVLTasks(PreTrainedModel):
     def __init__(self, config, task_cfg, task_ids, dropout_prob=0.1):
         super().__init__(config)
         self.bert = BertModel(config)
-        if dropout_prob != 0.1:
-            raise NotImplementedError("the engine's task heads use the reference's default dropout probability (0.1)")
+        if not 0.0 <= float(dropout_prob) < 1.0:
+            raise ValueError("dropout probability has to be between 0 and 1, but got {}".format(dropout_prob))
+        self.__dict__["_task_dropout"] = float(dropout_prob)      # nn.Dropout(dropout_prob) of the reference (encoders.py:1122): an engine op here
         self.task_cfg = task_cfg
         task2clf = {}
         for task_id in task_ids:
