@@ -214,6 +214,9 @@ typedef struct vk_attn_args {
     float scale;             /* 1/sqrt(head size) */
     int32_t dh;              /* head size: 0 or 64 -> the MFMA kernels (every ctrl_* config); 32, 96, 128 -> the generic kernels
                                 (config/vilbert_base.json: 8 heads of 128), column h * dh of q / k / v / ctx is head h */
+    float* probs[2][2];      /* NULL, or for block (query modality i, key modality j) fp32 [B, nh, L[i], L[j]]: the attention
+                                probabilities after dropout, as BertGatedSelfAttention returns them under config.visualization
+                                (volta/encoders.py:342-358).  Any non-NULL entry routes the forward to the generic kernels. */
 } vk_attn_args;
 typedef struct vk_attn_bwd_args {
     const void* dctx[2];     /* bf16 [B*L[m], ldo[m]] gradient of ctx */

@@ -589,6 +589,32 @@ def write_feature_reader():
     print("feature_reader", len(blob), "arrays", {str(v.dtype) for v in blob.values()}, os.path.getsize(path) // 1024, "KB")
 
 
+def write_attn_maps(BertConfig, Model):
+    """Attention maps of BertModel.forward(output_all_attention_masks=True) under config.visualization (volta/encoders.py:342-358,
+    858-886) for the tiny dual-stream and LXMERT-like configs: probabilities, query and key layers of every attention sub-layer."""
+    for name in ("tiny_vilbert", "tiny_lxmert", "tiny_gated"):
+        cd = dict(tiny_configs()[name], visualization=True)
+        cfg = R.RefConfig(cd)
+        sd = R.make_weights(cfg, seed=7)
+        batch = R.synthetic_batch(cfg, B=3, T=6, R=4, seed=11, pad=True)
+        model = Model(BertConfig.from_dict(cd))
+        model.load_state_dict(sd, strict=True)
+        model.eval()
+        with torch.no_grad():
+            out = model.bert(batch["input_ids"], batch["image_feat"].clone(), batch["image_loc"], batch["segment_ids"], batch["input_mask"],
+                             batch["image_mask"], output_all_attention_masks=True)
+        maps_t, maps_v = out[4]
+        blob = {"cfg_json": np.array(__import__("json").dumps(cd)), "n_layers": np.array([len(maps_t)])}
+        for tag, maps in (("t", maps_t), ("v", maps_v)):
+            for i, d in enumerate(maps):
+                for key in ("intra_attn", "inter_attn", "queries", "keys"):
+                    if d[key] is not None:
+                        blob["%s%d::%s" % (tag, i, key)] = d[key].numpy()
+        path = os.path.join(OUT, "attn_maps_" + name + ".npz")
+        np.savez_compressed(path, **blob)
+        print("attn_maps", name, len(maps_t), "attention sub-layers", os.path.getsize(path) // 1024, "KB")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     torch.manual_seed(0)
@@ -613,3 +639,5 @@ if __name__ == "__main__":
         write_concap()
     if which in ("all", "reader"):
         write_feature_reader()
+    if which in ("all", "attn"):
+        write_attn_maps(BertConfig, Model)

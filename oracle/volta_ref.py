@@ -267,7 +267,7 @@ def _merge(x):
     return x.transpose(1, 2).reshape(B, L, nh * dh)
 
 
-def gated_attention(sd, cfg, n, t, v, t_mask, v_mask, drop):
+def gated_attention(sd, cfg, n, t, v, t_mask, v_mask, drop, maps=None):
     """One attention sub-layer: projections, up to four score blocks, joint softmax per query
     modality, per-block dropout, summed contexts, output dense + dropout + residual + LN."""
     p = "bert.encoder.layer.%d." % n
@@ -289,6 +289,8 @@ def gated_attention(sd, cfg, n, t, v, t_mask, v_mask, drop):
         return q @ k.transpose(-1, -2) / math.sqrt(q.shape[-1]) + mask
 
     t_ctx = v_ctx = None
+    t_data = dict(intra_attn=None, inter_attn=None, queries=tq if has_t else None, keys=tk if has_t else None)      # encoders.py:342-356
+    v_data = dict(intra_attn=None, inter_attn=None, queries=vq if has_v else None, keys=vk if has_v else None)
     if has_t:
         blocks = []
         if has_tt:
@@ -296,7 +298,13 @@ def gated_attention(sd, cfg, n, t, v, t_mask, v_mask, drop):
         if has_tv:
             blocks.append((scores(tq, vk, v_mask), vv_))
         probs = torch.softmax(torch.cat([b[0] for b in blocks], -1), -1).split([b[0].shape[-1] for b in blocks], -1)
-        t_ctx = sum(_merge(drop(pr, cfg.attention_probs_dropout_prob) @ b[1]) for pr, b in zip(probs, blocks))
+        dropped_t = [drop(pr, cfg.attention_probs_dropout_prob) for pr in probs]
+        t_ctx = sum(_merge(pr @ b[1]) for pr, b in zip(dropped_t, blocks))
+        it = iter(dropped_t)
+        if has_tt:
+            t_data["intra_attn"] = next(it)
+        if has_tv:
+            t_data["inter_attn"] = next(it)
     if has_v:
         blocks = []
         if has_vt:
@@ -307,6 +315,14 @@ def gated_attention(sd, cfg, n, t, v, t_mask, v_mask, drop):
         # reference draws the vv mask before the vt mask (encoders.py:309-310); irrelevant in eval
         dropped = [drop(pr, cfg.v_attention_probs_dropout_prob) for pr in reversed(probs)][::-1]
         v_ctx = sum(_merge(pr @ b[1]) for pr, b in zip(dropped, blocks))
+        it = iter(dropped)
+        if has_vt:
+            v_data["inter_attn"] = next(it)
+        if has_vv:
+            v_data["intra_attn"] = next(it)
+    if maps is not None:
+        maps[0].append(t_data)
+        maps[1].append(v_data)
 
     o = p + "attention_output."
     t_out, v_out = t, v
@@ -380,7 +396,7 @@ def bert_model(sd, cfg, input_ids, image_feat, image_loc, token_type_ids=None, a
         taps["emb_t"], taps["emb_v"] = t, v
     for n, typ in sublayer_schedule(cfg):
         if typ == "attn":
-            t, v = gated_attention(sd, cfg, n, t, v, t_mask, v_mask, drop)
+            t, v = gated_attention(sd, cfg, n, t, v, t_mask, v_mask, drop, maps=taps.setdefault("attn_maps", ([], [])) if taps is not None else None)
         else:
             t, v = gated_ffn(sd, cfg, n, t, v, drop)
         if taps is not None:

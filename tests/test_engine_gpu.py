@@ -240,3 +240,54 @@ def test_bert_model_returns_every_sublayer_state(name):
             assert rel_err(got.cpu(), ref.detach()) < 2e-2, (name, key)
     with pytest.raises(NotImplementedError):
         model.bert(*args, output_all_attention_masks=True)
+
+
+@pytest.mark.parametrize("name", ["vilbert", "lxmert", "uniter"])
+@pytest.mark.parametrize("train", [False, True])
+def test_attention_maps_against_oracle(name, train):
+    """BertModel.forward(output_all_attention_masks=True) under config.visualization: per attention sub-layer the probabilities (after
+    dropout, replayed in the oracle), query and key layers of both modalities (volta/encoders.py:342-358, 858-886); without
+    config.visualization one None per attention sub-layer, without the flag empty lists.  The oracle's maps are pinned by the real
+    reference (tests/test_oracle_golden.py::test_attention_maps_match_reference)."""
+    from oracle import volta_ref as R
+    CONFIGS["_maps"] = dict(CONFIGS[name], visualization=True)
+    model, rcfg, sd = build("_maps")
+    batch = R.synthetic_batch(rcfg, 3, 20, 36, seed=7, pad=True)
+    seed = 0x5EED1234
+    model.train(train)
+    model.set_dropout_seed(seed)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    out = model.bert(cb["input_ids"], cb["image_feat"], cb["image_loc"], cb["segment_ids"], cb["input_mask"], cb["image_mask"],
+                     output_all_attention_masks=True)
+    torch.cuda.synchronize()
+    maps = out[4]
+    taps = {}
+    with torch.no_grad():
+        R.bert_model(sd, rcfg, batch["input_ids"], batch["image_feat"].clone(), batch["image_loc"], batch["segment_ids"], batch["input_mask"],
+                     batch["image_mask"], drop=R.Dropper(train, seed if train else None), taps=taps)
+    want = taps["attn_maps"]
+    assert len(maps[0]) == len(want[0]) and len(maps[1]) == len(want[1])
+    seen = 0
+    for side_g, side_w in zip(maps, want):
+        for dg, dw in zip(side_g, side_w):
+            for key in ("intra_attn", "inter_attn", "queries", "keys"):
+                if dw[key] is None:
+                    assert dg[key] is None, key
+                    continue
+                g, w = dg[key].float().cpu(), dw[key]
+                assert g.shape == w.shape, (key, g.shape, w.shape)
+                if key.endswith("attn"):
+                    assert float((g - w).abs().max()) <= 2e-2, (key, float((g - w).abs().max()))       # probabilities in [0, 1 / (1 - p)]
+                else:
+                    assert rel_err(g, w) <= 2e-2, (key, rel_err(g, w))
+                seen += 1
+    assert seen >= 4
+    # without config.visualization: one None per attention sub-layer; without the flag: empty lists
+    model2, _, _ = build(name)
+    model2.eval()
+    out2 = model2.bert(cb["input_ids"], cb["image_feat"], cb["image_loc"], cb["segment_ids"], cb["input_mask"], cb["image_mask"],
+                       output_all_attention_masks=True)
+    n_attn = len(want[0])
+    assert out2[4] == ([None] * n_attn, [None] * n_attn)
+    out3 = model2.bert(cb["input_ids"], cb["image_feat"], cb["image_loc"], cb["segment_ids"], cb["input_mask"], cb["image_mask"])
+    assert out3[4] == ([], [])

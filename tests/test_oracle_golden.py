@@ -270,3 +270,31 @@ def test_non_ctrl_config_matches_reference(golden_dir, name):
         np.testing.assert_allclose(got.numpy(), z["out::" + key], rtol=2e-5, atol=1e-6)
     np.testing.assert_allclose(taps["seq_t"].numpy()[:, :, :64], z["out::seq_t_slice"], rtol=0, atol=5e-5)
     np.testing.assert_allclose(taps["seq_v"].numpy()[:, :8, :64], z["out::seq_v_slice"], rtol=0, atol=5e-5)
+
+
+@pytest.mark.parametrize("name", ["tiny_vilbert", "tiny_lxmert", "tiny_gated"])
+def test_attention_maps_match_reference(golden_dir, name):
+    """The oracle's attention maps (probabilities, query and key layers per attention sub-layer) against the real reference's
+    BertModel.forward(output_all_attention_masks=True) under config.visualization (encoders.py:342-358, 858-886): what pins the checker of
+    the engine's attention-map output."""
+    z = load(golden_dir, "attn_maps_" + name)
+    cfg = R.RefConfig(json.loads(str(z["cfg_json"])))
+    sd = R.make_weights(cfg, seed=7)
+    batch = R.synthetic_batch(cfg, B=3, T=6, R=4, seed=11, pad=True)
+    taps = {}
+    with torch.no_grad():
+        R.bert_model(sd, cfg, batch["input_ids"], batch["image_feat"].clone(), batch["image_loc"], batch["segment_ids"], batch["input_mask"],
+                     batch["image_mask"], taps=taps)
+    maps = taps["attn_maps"]
+    assert len(maps[0]) == len(maps[1]) == int(z["n_layers"][0])
+    seen = 0
+    for tag, side in (("t", maps[0]), ("v", maps[1])):
+        for i, d in enumerate(side):
+            for key in ("intra_attn", "inter_attn", "queries", "keys"):
+                ref = z.get("%s%d::%s" % (tag, i, key))
+                if ref is None:
+                    assert d[key] is None, (tag, i, key)
+                else:
+                    np.testing.assert_allclose(d[key].numpy(), ref, rtol=0, atol=2e-6)
+                    seen += 1
+    assert seen > 0

@@ -151,7 +151,7 @@ class Op(C.Structure):
 class AttnArgs(C.Structure):
     _fields_ = [("q", c_p * 2), ("k", c_p * 2), ("v", c_p * 2), ("ld", i32 * 2), ("L", i32 * 2), ("mask", c_p * 2),
                 ("ctx", c_p * 2), ("ldo", i32 * 2), ("lse", c_p * 2), ("B", i32), ("nh", i32), ("gate", (i32 * 2) * 2),
-                ("drop", (Dropout * 2) * 2), ("scale", C.c_float), ("dh", i32)]
+                ("drop", (Dropout * 2) * 2), ("scale", C.c_float), ("dh", i32), ("probs", (c_p * 2) * 2)]
 
 
 class AttnBwdArgs(C.Structure):

@@ -561,6 +561,7 @@ extern "C" void vk_attn_set_force_generic(int v) { g_attn_force_generic = v; }
 static constexpr int g_attn_force_generic = 0;
 #endif
 static bool attn_mfma_ok(const vk_attn_args* a) {
+    if (a->probs[0][0] || a->probs[0][1] || a->probs[1][0] || a->probs[1][1]) return false;      // attention maps requested: the generic kernels write them
     for (int m = 0; m < 2; ++m) {             // rows beyond the MFMA kernels' tiles (64 text tokens, 128 regions): the generic kernels, at any head size
         const bool on = a->gate[m][0] || a->gate[m][1] || a->gate[0][m] || a->gate[1][m];
         if (on && a->L[m] > (m == 0 ? 64 : 128)) return false;

@@ -29,6 +29,7 @@ struct AttnG {
     const uint16_t* dctx[2];
     uint16_t* dq[2]; uint16_t* dk[2]; uint16_t* dv[2];
     int32_t ldg[2];
+    float* probs[2][2];       // forward only: attention probabilities (after dropout) of block (mq, mk), or NULL
 };
 
 constexpr int GW = 4;                      // waves per workgroup
@@ -124,6 +125,7 @@ __global__ __launch_bounds__(64 * GW) void attn_generic_fwd_kernel(const AttnG a
                 if (j < ntot) {
                     const int mk = j < n0 ? 0 : 1, k = j < n0 ? j : j - n0;
                     pbuf[j] = s[i] * inv * g_keep(a.drop[mq][mk], mk ? seed1 : seed0, drow, k);
+                    if (a.probs[mq][mk]) a.probs[mq][mk][(((size_t)b * a.nh + h) * Lq + q) * a.L[mk] + k] = pbuf[j];
                 }
             }
             float o0 = 0.f, o1 = 0.f;
@@ -338,6 +340,7 @@ int attn_generic(const vk_attn_args* a, const vk_attn_bwd_args* bw, vk_stream_t 
         k.dctx[m] = bw ? (const uint16_t*)bw->dctx[m] : nullptr;
         k.dq[m] = bw ? (uint16_t*)bw->dq[m] : nullptr; k.dk[m] = bw ? (uint16_t*)bw->dk[m] : nullptr;
         k.dv[m] = bw ? (uint16_t*)bw->dv[m] : nullptr; k.ldg[m] = bw ? bw->ldg[m] : 0;
+        for (int j = 0; j < 2; ++j) k.probs[m][j] = (!bw && a->gate[m][j]) ? a->probs[m][j] : nullptr;
     }
     k.B = a->B; k.nh = a->nh; k.scale = a->scale;
     for (int m = 0; m < 2; ++m) {

@@ -235,7 +235,7 @@ class StepEngine:
 
     H8_MUL = 8.0           # static scale of the fp8 copy of the GELU output: |h| <= 56 representable, 2^-9 absolute resolution near 0
 
-    def __init__(self, cfg, arena, B, T, Rv, train, heads="pretrain", fp8=False, task=None, task_dropout=0.1):
+    def __init__(self, cfg, arena, B, T, Rv, train, heads="pretrain", fp8=False, task=None, task_dropout=0.1, attn_maps=False):
         """fp8: the forward Q|K|V, FFN-up and FFN-down projections of every sub-layer run on the e4m3 MFMA path (csrc/fp8.hip); inputs are
         quantised per row right before the GEMM, weights per output channel whenever they change; the backward stays bf16.
         heads: "pretrain" = the three pre-training heads and losses (BertForVLPreTraining); "tasks" = poolers only, the
@@ -243,6 +243,8 @@ class StepEngine:
         self.cfg, self.arena, self.B, self.T, self.Rv, self.train = cfg, arena, B, T, Rv, train
         self.heads = heads
         self.task = task              # heads == "tasks": (task id, its task_cfg entry) -- the classifier built behind the poolers
+        self.attn_maps = bool(attn_maps)      # keep every attention sub-layer's probabilities (config.visualization, encoders.py:342-358): generic attention kernels
+        self.attn_map_info = []
         self.task_dropout = float(task_dropout)      # BertForVLTasks(dropout_prob=...): nn.Dropout on the fused pooled vector / region states (encoders.py:1118-1122)
         self.fp8 = bool(fp8)
         dev = arena.device
@@ -959,6 +961,14 @@ class StepEngine:
                 for j in range(2):
                     aa.gate[i][j] = gl[i][j]
                     aa.drop[i][j] = drops.get((i, j), L.dropout_cfg(None, 0, 0.0)) if gl[i][j] else L.dropout_cfg(None, 0, 0.0)
+            if self.attn_maps:
+                pb = {}
+                for i in range(2):
+                    for j in range(2):
+                        if gl[i][j]:
+                            pb[(i, j)] = self.buf(tag + "probs%d%d" % (i, j), (B, nhm[m0], self.st[i].L, self.st[j].L), torch.float32)
+                            aa.probs[i][j] = pb[(i, j)].data_ptr()
+                self.attn_map_info.append(dict(n=n, probs=pb, qkv={m: qkv[m] for m in mq}, Ha={m: Ha[m] for m in mq}, nh=nhm[m0], dh=dh[m0]))
             self.k(aa)
             f.append((L.OP_ATTN_FWD, 0, 0, 0, aa, None, None))
             attn.append((aa, mq, gl))
@@ -1540,6 +1550,27 @@ class StepEngine:
         return b
 
     # ---------------------------------------------------------------- run
+    def attention_maps(self):
+        """(all_attention_mask_t, all_attention_mask_v) of BertEncoder.forward (volta/encoders.py:858-886) under config.visualization: per
+        attention sub-layer and modality {"intra_attn", "inter_attn", "queries", "keys"} -- probabilities [B, heads, Lq, Lk] after dropout,
+        query / key layers [B, heads, L, head size] (encoders.py:342-356); None where the modality takes no part.  Launches of a sub-layer
+        whose streams differ in head geometry are listed one after the other."""
+        out = ([], [])
+        for info in self.attn_map_info:
+            nh, dh = info["nh"], info["dh"]
+            for m in range(2):
+                if m not in info["qkv"]:
+                    out[m].append({"intra_attn": None, "inter_attn": None, "queries": None, "keys": None})
+                    continue
+                qkv, Ha = info["qkv"][m], info["Ha"][m]
+                Lm = self.st[m].L
+                heads = lambda t: t.view(self.B, Lm, nh, dh).transpose(1, 2).float()
+                p = info["probs"]
+                out[m].append({"intra_attn": p[(m, m)].clone() if (m, m) in p else None,
+                               "inter_attn": p[(m, 1 - m)].clone() if (m, 1 - m) in p else None,
+                               "queries": heads(qkv[:, :Ha]), "keys": heads(qkv[:, Ha:2 * Ha])})
+        return out
+
     def fwd_segments(self, bounds):
         """Cut the forward list for an optimizer that is still updating the arena in `bounds` = [chunk index where range r ends] (ranges in
         arena order = forward order): [(ranges that must be complete, op start, op end)].  The embeddings need what lies before the first

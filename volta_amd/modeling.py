@@ -188,10 +188,8 @@ class BertModel(PreTrainedModel):
         root = self.__dict__.get("_root")
         if root is None:
             raise NotImplementedError("BertModel runs as part of BertForVLPreTraining (the HIP plan includes the heads)")
-        if output_all_attention_masks:
-            raise NotImplementedError("attention maps are not materialised by the fused attention kernel")
         return root.encode(input_txt, input_imgs, image_loc, token_type_ids, attention_mask, image_attention_mask,
-                           output_all_encoded_layers=output_all_encoded_layers)
+                           output_all_encoded_layers=output_all_encoded_layers, output_all_attention_masks=output_all_attention_masks)
 
 
 class BertPreTrainingHeads(M.Holder):
@@ -295,14 +293,15 @@ class BertForVLPreTraining(PreTrainedModel):
         arena = self.materialize()
         fp8 = bool(self.__dict__.get("_fp8", False))
         task_id = self.__dict__.get("_cur_task")
-        key = (B, T, Rv, bool(train), fp8, task_id)
+        maps = bool(self.__dict__.get("_want_attn_maps", False))
+        key = (B, T, Rv, bool(train), fp8, task_id, maps)
         eng = self._engines.get(key)
         if eng is None:
-            for k in [k for k in self._engines if k[3] == key[3] and k[5] == task_id]:      # one plan per mode (and task head) keeps memory bounded
+            for k in [k for k in self._engines if k[3] == key[3] and k[5] == task_id and k[6] == maps]:      # one plan per mode (and task head) keeps memory bounded
                 del self._engines[k]
             task = (task_id, self.task_cfg[task_id]) if task_id is not None else None
             eng = StepEngine(self.config, arena, B, T, Rv, train, heads=getattr(self, "_heads_mode", "pretrain"), fp8=fp8, task=task,
-                             task_dropout=self.__dict__.get("_task_dropout", 0.1))
+                             task_dropout=self.__dict__.get("_task_dropout", 0.1), attn_maps=maps)
             self._engines[key] = eng
         return eng
 
@@ -430,11 +429,11 @@ class BertForVLPreTraining(PreTrainedModel):
                 image_attention_mask=None, masked_lm_labels=None, image_label=None, image_cls=None, obj_labels=None,
                 obj_confs=None, attr_labels=None, attr_confs=None, image_attrs=None, next_sentence_label=None,
                 output_all_attention_masks=False):
-        if output_all_attention_masks:
-            raise NotImplementedError("attention maps are never materialised by the fused attention kernel")
+        # (with losses the reference returns the three losses only, encoders.py:1111-1112: the attention maps are not part of that result)
         if masked_lm_labels is None and next_sentence_label is None:
             # encoders.py:1113-1114: without text labels and without a masked region every loss is zero and the reference returns the heads' scores
-            return self._scores(input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask, image_label)
+            return self._scores(input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask, image_label,
+                                output_all_attention_masks)
         if masked_lm_labels is None or image_label is None:
             raise NotImplementedError("the pre-training step needs masked_lm_labels and image_label")
         tensors, B, T, Rv = self._prep_inputs(input_ids, image_feat, image_loc, token_type_ids, attention_mask,
@@ -447,7 +446,7 @@ class BertForVLPreTraining(PreTrainedModel):
         losses = self._engine_forward(tensors)
         return losses[0:1].clone(), losses[1:2].clone(), losses[2:3].clone()
 
-    def _scores(self, input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask, image_label):
+    def _scores(self, input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask, image_label, output_all_attention_masks=False):
         """The score-returning branch of BertForVLPreTraining.forward (volta/encoders.py:1065-1068,1113-1114): (prediction_scores_t [B,T,V],
         {target: prediction_scores_v [B,Rv,C]}, seq_relationship_score [B,2] or None, attention maps = ([], []), pooled_output or None), the heads
         applied to EVERY position.  Inference only (no gradient, the heads' dropout is the identity); the projections run on the library's GEMM /
@@ -459,7 +458,8 @@ class BertForVLPreTraining(PreTrainedModel):
             was_training = self.training
             self.eval()
             try:
-                seq_t, seq_v, pt, pv, _ = self.encode(input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask)
+                seq_t, seq_v, pt, pv, attn_maps = self.encode(input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask,
+                                                              output_all_attention_masks=output_all_attention_masks)
             finally:
                 self.train(was_training)
             eng = self._last[0]
@@ -504,10 +504,10 @@ class BertForVLPreTraining(PreTrainedModel):
                 sc = torch.empty(B, 64, device=dev)
                 ops.gemm_grouped(L.NT, L.EPI_F32, [ops.gemm_problem(pb, W("cls.bi_seq_relationship.weight"), sc, L.NT, B, 2, P, bias=Pm("cls.bi_seq_relationship.bias"), n_store=64)])
                 itm = sc[:, :2]
-            return scores_t, scores_v, itm, ([], []), pooled
+            return scores_t, scores_v, itm, attn_maps, pooled
 
     def encode(self, input_ids, image_feat, image_loc, token_type_ids=None, attention_mask=None, image_attention_mask=None,
-               output_all_encoded_layers=False):
+               output_all_encoded_layers=False, output_all_attention_masks=False):
         """BertModel.forward: (seq_t [B,T,H], seq_v [B,Rv,H], pooled_t, pooled_v, attention maps = ([], [])); with
         `output_all_encoded_layers` the two sequences are lists with both streams' states after EVERY sub-layer (encoders.py:868-881)."""
         B, T = input_ids.shape
@@ -519,9 +519,14 @@ class BertForVLPreTraining(PreTrainedModel):
                      obj_labels=torch.zeros(B, R, dtype=torch.int64, device=dev), obj_confs=torch.zeros(B, R, device=dev),
                      attr_labels=torch.zeros(B, R, dtype=torch.int64, device=dev), attr_confs=torch.zeros(B, R, device=dev))
         tensors, B, T, Rv = self._prep_inputs(input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask, **dummy)
-        with torch.no_grad():
-            self._engine_forward(tensors)
+        self.__dict__["_want_attn_maps"] = bool(output_all_attention_masks and self.config.visualization)
+        try:
+            with torch.no_grad():
+                self._engine_forward(tensors)
+        finally:
+            self.__dict__["_want_attn_maps"] = False
         eng = self._last[0]
+        attn_maps = _attention_maps(self.config, eng, output_all_attention_masks)
         H = self.config.hidden_size
         pt, pv = eng.taps["pooled_t"], eng.taps["pooled_v"]          # None where the fusion method has no such pooler
         Hv = self.config.v_hidden_size
@@ -530,7 +535,18 @@ class BertForVLPreTraining(PreTrainedModel):
             seq_v = [eng.taps["v%d" % n].view(B, Rv, Hv).float() for n in eng.sublayer_ids]
         else:
             seq_t, seq_v = eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, Hv).float()
-        return seq_t, seq_v, None if pt is None else pt.float(), None if pv is None else pv.float(), ([], [])
+        return seq_t, seq_v, None if pt is None else pt.float(), None if pv is None else pv.float(), attn_maps
+
+
+def _attention_maps(config, eng, requested):
+    """all_attention_mask of BertEncoder.forward (volta/encoders.py:858-886): empty lists unless requested; one entry per attention
+    sub-layer otherwise -- the dictionaries of encoders.py:342-356 under config.visualization, None without it (:357-358)."""
+    if not requested:
+        return ([], [])
+    if config.visualization:
+        return eng.attention_maps()
+    n = sum(1 for _, typ in M.sublayer_schedule(config) if typ == "attn")
+    return ([None] * n, [None] * n)
 
 
 # ======================================================================================== downstream tasks
@@ -638,13 +654,18 @@ class BertForVLTasks(PreTrainedModel):
             p._vk_owner = self
 
     def encode(self, input_ids, image_feat, image_loc, token_type_ids=None, attention_mask=None, image_attention_mask=None,
-               output_all_encoded_layers=False):
+               output_all_encoded_layers=False, output_all_attention_masks=False):
         """BertModel.forward under no_grad (BertModel.forward delegates here)."""
         tensors, B, T, Rv = self._prep_inputs(input_ids, image_feat, image_loc, token_type_ids, attention_mask, image_attention_mask,
                                               None, None, None, None)
-        with torch.no_grad():
-            self._engine_forward(tensors)
+        self.__dict__["_want_attn_maps"] = bool(output_all_attention_masks and self.config.visualization)
+        try:
+            with torch.no_grad():
+                self._engine_forward(tensors)
+        finally:
+            self.__dict__["_want_attn_maps"] = False
         eng = self._last[0]
+        attn_maps = _attention_maps(self.config, eng, output_all_attention_masks)
         H = self.config.hidden_size
         pt, pv = eng.taps["pooled_t"], eng.taps["pooled_v"]          # None where the fusion method has no such pooler
         Hv = self.config.v_hidden_size
@@ -653,17 +674,16 @@ class BertForVLTasks(PreTrainedModel):
             seq_v = [eng.taps["v%d" % n].view(B, Rv, Hv).float() for n in eng.sublayer_ids]
         else:
             seq_t, seq_v = eng.taps["seq_t"].view(B, T, H).float(), eng.taps["seq_v"].view(B, Rv, Hv).float()
-        return seq_t, seq_v, None if pt is None else pt.float(), None if pv is None else pv.float(), ([], [])
+        return seq_t, seq_v, None if pt is None else pt.float(), None if pv is None else pv.float(), attn_maps
 
     def forward(self, input_txt, input_imgs, image_loc, task_id, token_type_ids=None, attention_mask=None,
                 image_attention_mask=None, output_all_encoded_layers=False, output_all_attention_masks=False):
-        if output_all_attention_masks:
-            raise NotImplementedError("attention maps are not materialised by the fused attention kernel")
         if task_id not in self.task_cfg or task_id not in self.clfs_dict:
             raise KeyError("unknown task id %r" % (task_id,))
         tensors, B, T, Rv = self._prep_inputs(input_txt, input_imgs, image_loc, token_type_ids, attention_mask, image_attention_mask,
                                               None, None, None, None)
         self.__dict__["_cur_task"] = task_id                    # selects the plan whose head is this task's classifier
+        self.__dict__["_want_attn_maps"] = bool(output_all_attention_masks and self.config.visualization)
         try:
             self.materialize()
             if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
@@ -677,7 +697,9 @@ class BertForVLTasks(PreTrainedModel):
                 vil_prediction = eng.pred[:, :C].reshape(eng.pred_shape).clone()
         finally:
             self.__dict__["_cur_task"] = None
+            self.__dict__["_want_attn_maps"] = False
+        attn_maps = _attention_maps(self.config, self._last[0], output_all_attention_masks)
         if self.task_cfg[task_id]["type"].startswith("V-logit"):   # padded regions are masked out of the region scores (encoders.py:1198-1199)
             mask = tensors["image_attention_mask"].to(vil_prediction.dtype)
             vil_prediction = vil_prediction + ((1.0 - mask) * -10000.0).unsqueeze(2)
-        return vil_prediction, None, None, ([], [])
+        return vil_prediction, None, None, attn_maps
