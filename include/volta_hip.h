@@ -509,9 +509,6 @@ int vk_side_join(vk_stream_t s);
 int vk_side_join_from(vk_stream_t owner, vk_stream_t waiter);
 /* 0: run side-stream blocks inline on the caller's stream (serial schedule); 1 (default): concurrently. */
 void vk_side_enable(int on);
-/* Scheduling priority of side streams created AFTER the call, relative to the caller's stream: 0 = default priority, 1 = the
-   device's lowest (the weight-gradient blocks then only take the CUs the main chain leaves free).  Process-wide switch. */
-void vk_side_set_low_priority(int on);
 
 /* ------------------------------------------------------------------------------------------------
  * ConceptCap batch producer: raw records -> the model's input tensors with the reference's sampling policy.

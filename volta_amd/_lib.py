@@ -252,7 +252,6 @@ _sig("vk_concap_batch", C.c_int, C.POINTER(ConcapArgs), c_p)
 _sig("vk_side_join", C.c_int, c_p)
 _sig("vk_side_join_from", C.c_int, c_p, c_p)
 _sig("vk_side_enable", None, C.c_int)
-_sig("vk_side_set_low_priority", None, C.c_int)
 
 EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_cast_f32_bf16", "vk_gemm_grouped", "vk_gemm_grouped_ex", "vk_gemm_split_workspace_bytes", "vk_gemm_fp8_grouped", "vk_quant_rows_fp8", "vk_cast_bf16_fp8",
            "vk_ln_fwd", "vk_ln_fwd_pair", "vk_ln_bwd_partial_rows", "vk_ln_bwd", "vk_ln_bwd_pair", "vk_ln_bwd_finalize", "vk_gated_attn_fwd", "vk_gated_attn_bwd",
@@ -262,7 +261,7 @@ EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_c
            "vk_xent_bwd", "vk_kl_fwd", "vk_kl_bwd", "vk_loss_finalize", "vk_pool_mul_fwd", "vk_pool_mul_bwd",
            "vk_pool_fuse_fwd", "vk_pool_fuse_bwd", "vk_text_end_rows", "vk_vlbert_obj_ids", "vk_vlbert_positions", "vk_vis_loss_fwd", "vk_vis_loss_bwd", "vk_nce_negatives",
            "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_grad_norm_clip_masked", "vk_grad_sqnorm_chunks", "vk_grad_norm_from_chunks", "vk_adamw_step",
-           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_side_tail", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_join_from", "vk_side_enable", "vk_side_set_low_priority", "vk_concap_batch",
+           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_side_tail", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_join_from", "vk_side_enable", "vk_concap_batch",
            "vk_lmdb_open", "vk_lmdb_close", "vk_lmdb_entries", "vk_lmdb_first", "vk_lmdb_next", "vk_lmdb_get", "vk_concap_record_decode", "vk_concap_records_decode", "vk_b64_decode",
            "vk_wordpiece_open", "vk_wordpiece_close", "vk_wordpiece_vocab_size", "vk_wordpiece_token_id", "vk_wordpiece_encode", "vk_wordpiece_encode_batch"]
 
