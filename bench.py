@@ -310,8 +310,21 @@ def main():
         t = torch.tensor([elapsed], device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t)
+    # Host WORK per step: the same step issued into an EMPTY queue (synchronise first), on every rank alike.  `host_issue_ms_per_step` above
+    # is the wall time of the issuing loop, which the bounded HIP queues throttle to the GPU's pace once they are full -- it approaches
+    # ms_per_step by construction and says nothing about host cost; this figure does.
+    host_work = []
+    for _ in range(3):
+        fence()
+        th = time.perf_counter()
+        step()
+        host_work.append(time.perf_counter() - th)
+    fence()
     gflop = GFLOP_PER_PAIR.get((a.config, a.seq_len, a.regions))
     out, ms, pairs_s = result_line(a, world, elapsed, t_issue, {
+        "host_work_ms_per_step": min(host_work) * 1e3,
+        "host_note": "host_work = one step issued into an empty queue (the host's own cost); host_issue = wall time of the issuing loop, throttled "
+                     "by queue back-pressure to the GPU's pace",
         **({"rehearsal": "all ranks share cuda:0 over gloo: timings are meaningless"} if shared else {}),
         "losses_last_step": [float(x.detach()) for x in losses]})
     if rank == 0:

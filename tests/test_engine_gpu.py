@@ -102,7 +102,8 @@ def _parity(name, train, B, T, Rn, batch_seed=7, max_pos=None):
         assert e < 2e-2, (name, key, e)
     # ---- losses.  Tolerances (bf16 activations, fp32 accumulation): MLM / region / total loss 1e-3 relative (north_star);
     # the ITM loss averages only B = 4 samples of bf16-noisy logits here (1e-2); the contract check of the ITM loss is the
-    # B = 256 reference fixture (tests/test_fullsize_golden_gpu.py, 1e-3).
+    # B = 256 reference fixture (tests/test_fullsize_golden_gpu.py: 1.5e-3 against the fp32 reference, of which 6.8e-4 is the bf16 weight
+    # format itself and 3.6e-4 the engine's arithmetic -- test_itm_error_budget_weight_format_vs_engine_arithmetic).
     for got, ref, nm in ((lm, olm, "lm"), (img, oimg, "img"), (nsp, onsp, "nsp")):
         g, r = float(got.detach()), float(ref.detach())
         tol = 1e-2 if nm == "nsp" else 1e-3

@@ -15,7 +15,6 @@ vv, vt probabilities, text output, vision output; pooled) -- the contract the ma
 """
 import ctypes as C
 import math
-import os
 
 import torch
 
@@ -1109,11 +1108,10 @@ class StepEngine:
         # K-chunk length: ~5120 rows, halved (down to ~1280) while the whole group still yields fewer than ~200 tiles of 256 x 256 -- the
         # attention sub-layers' group ([768, 768] and [2304, 768] outputs) is 108 tiles of 150 K-steps at 5120, i.e. 42 % of the CUs
         # busy for 127 us; more, shorter chunks fill the chip (the extra slabs cost the tail launch a few microseconds)
-        chunk_rows = float(os.environ.get('VK_WGRAD_CHUNK', '5120'))
-        if 'VK_WGRAD_CHUNK' not in os.environ:
-            tiles = lambda cr: sum(-(-Mo // 256) * -(-No // 256) * sum(max(1, int(round(rows / cr))) for _, _, rows, _, _ in srcs) for _, _, Mo, No, srcs in jobs)
-            while chunk_rows > 1280 and tiles(chunk_rows) < 200:
-                chunk_rows /= 2
+        chunk_rows = 5120.0
+        tiles = lambda cr: sum(-(-Mo // 256) * -(-No // 256) * sum(max(1, int(round(rows / cr))) for _, _, rows, _, _ in srcs) for _, _, Mo, No, srcs in jobs)
+        while chunk_rows > 1280 and tiles(chunk_rows) < 200:
+            chunk_rows /= 2
         probs, reduces = [], []
         for gW, gB, Mo, No, srcs in jobs:
             chunks = []
