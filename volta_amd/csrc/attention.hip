@@ -143,14 +143,23 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     constexpr int RB = 2 * DHT, KS = DHT / 32, DT = DHT / 16;      // image row bytes, 32-deep contraction steps, 16-wide output tiles per head
     const uint32_t kimg[2] = {lds0, lds0 + TP * RB};
     const uint32_t vimg[2] = {lds0 + (TP + RP) * RB, lds0 + (TP + RP) * RB + TP * RB};
+    const uint32_t qimg[2] = {lds0 + 2 * (TP + RP) * RB, lds0 + 2 * (TP + RP) * RB + TP * RB};
+    // additive key masks of this batch element as floats behind the images: [TP | RP]
+    float VK_LDS* const mask_s = (float VK_LDS*)(uintptr_t)(lds0 + 3 * (TP + RP) * RB);
+    constexpr int MB[2] = {0, TP};
     const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
     const int b = blockIdx.x / a.nh, h = blockIdx.x - b * a.nh;
     const int g = lane >> 4, lq = lane & 15;
 
+    // Everything a task reads is staged up front -- K, V, Q rows and the key masks -- so that the task loop makes no global load: with Q rows
+    // and masks fetched inside the loop every task began with two more dependent memory round trips.
     {
         const int nthr = blockDim.x;
         const bool k0 = a.gate[0][0] || a.gate[1][0], k1 = a.gate[0][1] || a.gate[1][1];
+        const bool q0 = a.gate[0][0] || a.gate[0][1], q1 = a.gate[1][0] || a.gate[1][1];
         u32x4 rk0[StagePieces<TP, DHT>::N], rv0[StagePieces<TP, DHT>::N], rk1[StagePieces<RP, DHT>::N], rv1[StagePieces<RP, DHT>::N];
+        u32x4 rq0[StagePieces<TP, DHT>::N], rq1[StagePieces<RP, DHT>::N];
+        float mk = 0.f;
         if (k0) {
             stage_load<TP, DHT>(rk0, a.k[0] + ((size_t)b * a.L[0]) * a.ld[0] + h * DHT, a.ld[0], a.L[0], tid, nthr);
             stage_load<TP, DHT>(rv0, a.v[0] + ((size_t)b * a.L[0]) * a.ld[0] + h * DHT, a.ld[0], a.L[0], tid, nthr);
@@ -159,9 +168,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             stage_load<RP, DHT>(rk1, a.k[1] + ((size_t)b * a.L[1]) * a.ld[1] + h * DHT, a.ld[1], a.L[1], tid, nthr);
             stage_load<RP, DHT>(rv1, a.v[1] + ((size_t)b * a.L[1]) * a.ld[1] + h * DHT, a.ld[1], a.L[1], tid, nthr);
         }
+        if (q0) stage_load<TP, DHT>(rq0, a.q[0] + ((size_t)b * a.L[0]) * a.ld[0] + h * DHT, a.ld[0], a.L[0], tid, nthr);
+        if (q1) stage_load<RP, DHT>(rq1, a.q[1] + ((size_t)b * a.L[1]) * a.ld[1] + h * DHT, a.ld[1], a.L[1], tid, nthr);
+        if (tid < TP) { if (k0 && tid < a.L[0]) mk = a.mask[0][(size_t)b * a.L[0] + tid]; }
+        else if (tid < TP + RP) { if (k1 && tid - TP < a.L[1]) mk = a.mask[1][(size_t)b * a.L[1] + (tid - TP)]; }
         if (k0) { stage_store<TP, DHT>(kimg[0], rk0, tid, nthr); stage_store<TP, DHT>(vimg[0], rv0, tid, nthr); }
         if (k1) { stage_store<RP, DHT>(kimg[1], rk1, tid, nthr); stage_store<RP, DHT>(vimg[1], rv1, tid, nthr); }
-        if (tid == 0) *(int VK_LDS*)(uintptr_t)(lds0 + 2 * (TP + RP) * RB) = 0;
+        if (q0) stage_store<TP, DHT>(qimg[0], rq0, tid, nthr);
+        if (q1) stage_store<RP, DHT>(qimg[1], rq1, tid, nthr);
+        if (tid < TP + RP) mask_s[tid] = mk;
+        if (tid == 0) *(int VK_LDS*)(uintptr_t)(lds0 + 3 * (TP + RP) * RB + (TP + RP) * 4) = 0;
     }
     __syncthreads();
 
@@ -169,7 +185,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     const int nqt1 = (a.gate[1][0] || a.gate[1][1]) ? (a.L[1] + 15) / 16 : 0;
     // Tasks (16-query tiles) are claimed from a counter in LDS, vision tiles (more keys per tile) first: 5 tiles on 4 waves in fixed
     // round-robin order left one wave with text + vision tile while the others idled.
-    int VK_LDS* const next_task = (int VK_LDS*)(uintptr_t)(lds0 + 2 * (TP + RP) * RB);
+    int VK_LDS* const next_task = (int VK_LDS*)(uintptr_t)(lds0 + 3 * (TP + RP) * RB + (TP + RP) * 4);
     (void)nwaves;
     for (;;) {
         int task = 0;
@@ -182,10 +198,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
         const int qi = qt * 16 + lq;
         const bool qvalid = qi < Lq;
         const int qc = qvalid ? qi : Lq - 1;
-        const uint16_t* qrow = a.q[mq] + ((size_t)b * Lq + qc) * a.ld[mq] + h * DHT;
         bf16x8 qf[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) qf[ks] = *(const bf16x8*)(qrow + ks * 32 + g * 8);
+        for (int ks = 0; ks < KS; ++ks) qf[ks] = img_row_frag<DHT>(qimg[mq], qt * 16, ks, lane);      // rows past Lq are zero: their results are dropped
 
         f32x4 s0[NKT[0]], s1[NKT[1]];
         float mx = -INFINITY;
@@ -200,7 +215,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                 _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
                     const int key = kt * 16 + 4 * g + r;                                                   \
                     if (key < a.L[MK]) {                                                                   \
-                        S[kt][r] = acc[r] * a.scale + a.mask[MK][(size_t)b * a.L[MK] + key];               \
+                        S[kt][r] = acc[r] * a.scale + mask_s[MB[MK] + key];                                \
                         mx = fmaxf(mx, S[kt][r]);                                                          \
                     }                                                                                      \
                 }                                                                                          \
@@ -277,6 +292,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     const uint32_t gimg[2] = {vimg[0] + ROWS * RB, vimg[1] + ROWS * RB};
     float VK_LDS* lse_s = (float VK_LDS*)(uintptr_t)(lds0 + 4 * ROWS * RB);
     float VK_LDS* del_s = lse_s + ROWS;
+    float VK_LDS* const mask_s = del_s + ROWS;                 // additive key masks of this batch element, [TP | RP]
     const int rbase[2] = {0, TP};
     const int tid = threadIdx.x, lane = tid & 63, nwaves = blockDim.x >> 6;
     const int b = blockIdx.x / a.nh, h = blockIdx.x - b * a.nh;
@@ -311,6 +327,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             stage_load<RP, DHT>(rg1, a.dctx[1] + r1 * a.ldo[1] + h * DHT, a.ldo[1], a.L[1], tid, nthr);
             stage_load<RP, DHT>(ro1, a.ctx[1] + r1 * a.ldo[1] + h * DHT, a.ldo[1], a.L[1], tid, nthr);
         }
+        float mkv = 0.f;
+        if (tid < ROWS) {
+            const int m = tid < TP ? 0 : 1, key = tid - rbase[m];
+            if (kact[m] && key < a.L[m]) mkv = a.mask[m][(size_t)b * a.L[m] + key];
+        }
         if (kact[0]) { stage_store<TP, DHT>(kimg[0], rk0, tid, nthr); stage_store<TP, DHT>(vimg[0], rv0, tid, nthr); }
         if (qact[0]) {
             stage_store<TP, DHT>(qimg[0], rq0, tid, nthr); stage_store<TP, DHT>(gimg[0], rg0, tid, nthr);
@@ -321,7 +342,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             stage_store<RP, DHT>(qimg[1], rq1, tid, nthr); stage_store<RP, DHT>(gimg[1], rg1, tid, nthr);
             delta_rows<RP, DHT>(rg1, ro1, del_s + rbase[1], lse_s + rbase[1], a.lse[1] + ((size_t)b * a.nh + h) * a.L[1], a.L[1], tid, nthr);
         }
-        if (tid == 0) *(int VK_LDS*)(uintptr_t)(lds0 + 4 * ROWS * RB + 2 * ROWS * 4) = 0;
+        if (tid < ROWS) mask_s[tid] = mkv;
+        if (tid == 0) *(int VK_LDS*)(uintptr_t)(lds0 + 4 * ROWS * RB + 3 * ROWS * 4) = 0;
     }
     __syncthreads();
 
@@ -331,7 +353,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
     // Tasks are claimed from a counter in LDS in the order key tiles (two accumulators: the heavier role) before query tiles, vision
     // before text: 10 tasks of unequal weight on 4 waves in fixed round-robin order left one wave with 4.5 units of work against 3.5 on
     // average.
-    int VK_LDS* const next_task = (int VK_LDS*)(uintptr_t)(lds0 + 4 * ROWS * RB + 2 * ROWS * 4);
+    int VK_LDS* const next_task = (int VK_LDS*)(uintptr_t)(lds0 + 4 * ROWS * RB + 3 * ROWS * 4);
     (void)nwaves;
     for (;;) {
         int task = 0;
@@ -345,7 +367,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
             const int Lk = a.L[mk];
             const int key = kt * 16 + lq;
             const bool kvalid = key < Lk;
-            const float kmask = kvalid ? a.mask[mk][(size_t)b * Lk + key] : 0.f;
+            const float kmask = kvalid ? mask_s[rbase[mk] + key] : 0.f;
             bf16x8 kf[KS], vf[KS];
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) { kf[ks] = img_row_frag<DHT>(kimg[mk], kt * 16, ks, lane); vf[ks] = img_row_frag<DHT>(vimg[mk], kt * 16, ks, lane); }
@@ -450,7 +472,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(OCC, OCC)))
                                 const int key = kt * 16 + 4 * g + r;                                       \
                                 float v = 0.f;                                                             \
                                 if (key < Lk && qvalid) {                                                  \
-                                    const float p = __expf(s[r] * a.scale + a.mask[MK][(size_t)b * Lk + key] - lse); \
+                                    const float p = __expf(s[r] * a.scale + mask_s[rbase[MK] + key] - lse);      \
                                     const float keep = (w[r] >= dc.threshold) ? dc.scale : 0.f;            \
                                     v = p * (dp[r] * keep - delta);                                        \
                                 }                                                                          \
@@ -512,7 +534,7 @@ VK_ATTN_TUNABLE g_attn_fwd_waves = 4;    // waves per workgroup (query tiles are
 VK_ATTN_TUNABLE g_attn_fwd_occ = 4;      // tuning hook: waves per SIMD the register allocation targets (5 spills 16-74 dwords: slower)
 template <int TP, int RP, int DHT>
 static int launch_fwd(const AttnK& k, int nq_tiles, hipStream_t s) {
-    const int lds = 2 * (TP + RP) * 2 * DHT + 16;          // + the task counter
+    const int lds = 3 * (TP + RP) * 2 * DHT + (TP + RP) * 4 + 16;          // K, V, Q images, key masks, the task counter
     int waves = nq_tiles < 4 ? 4 : (nq_tiles > 8 ? 8 : nq_tiles);      // staging is sized for >= 256 threads
     if (g_attn_fwd_waves >= 4 && g_attn_fwd_waves < waves && 4 * lds <= 160 * 1024) waves = g_attn_fwd_waves;     // only where four workgroups fit the CU's LDS
     if (DHT == 64 && g_attn_fwd_occ == 5) {
@@ -529,7 +551,7 @@ VK_ATTN_TUNABLE g_attn_bwd_occ = 3;      // waves per SIMD the register allocati
 
 template <int TP, int RP, int DHT>
 static int launch_bwd(const AttnK& k, int ntasks, hipStream_t s) {
-    const int lds = 4 * (TP + RP) * 2 * DHT + 2 * (TP + RP) * 4 + 16;          // + the task counter
+    const int lds = 4 * (TP + RP) * 2 * DHT + 3 * (TP + RP) * 4 + 16;          // four images, lse / delta / key masks, the task counter
     if (DHT == 64 && g_attn_bwd_occ == 3 && 3 * lds <= 160 * 1024) {       // three workgroups only fit with the small images
         auto kern = attn_bwd_kernel<TP, RP, 3, DHT>;
         static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); (void)attr;      // once per process, thread-safe
@@ -545,7 +567,7 @@ static int launch_bwd(const AttnK& k, int ntasks, hipStream_t s) {
 }
 
 // LDS of the backward's four images per row (+ statistics): what decides whether 128-wide heads fit the MFMA kernel
-static bool bwd_fits(int TP, int RP, int dht) { return 4 * (TP + RP) * 2 * dht + 2 * (TP + RP) * 4 + 16 <= 160 * 1024; }
+static bool bwd_fits(int TP, int RP, int dht) { return 4 * (TP + RP) * 2 * dht + 3 * (TP + RP) * 4 + 16 <= 160 * 1024; }
 
 }  // namespace vk
 
