@@ -7,8 +7,9 @@ import os
 import torch  # noqa: F401  -- must come first: libvolta_hip.so has to bind to the HIP runtime torch already loaded
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# VK_LIB=study loads the measurement build (tools/ only: ablation switches, geometry overrides, the 4-phase study kernel)
-LIB_PATH = os.path.join(_HERE, "libvolta_hip_study.so" if os.environ.get("VK_LIB") == "study" else "libvolta_hip.so")
+# VK_LIB=study loads the measurement build (tools/ only: ablation switches, geometry overrides, the 4-phase study kernel); any other
+# name loads libvolta_hip_<name>.so, a second build of the same sources for an A/B in one box session (tools/ab_bench.sh)
+LIB_PATH = os.path.join(_HERE, "libvolta_hip_%s.so" % os.environ["VK_LIB"] if os.environ.get("VK_LIB") else "libvolta_hip.so")
 GEMM_PERSISTENT, GEMM_ONE_TILE_PER_WG = 0x1000, 0x2000
 
 

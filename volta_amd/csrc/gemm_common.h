@@ -183,8 +183,11 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
                     if ((RPI * CPR < 64 && rr0 >= RPI) || ((RPH % RPI) && row >= RPH)) continue;
                     const uint32_t a = row * PITCH + ((ch ^ (row & SWZ)) << 4);
                     const size_t g = ((size_t)(mrow0 + row) * ldc + (size_t)n_base) * ES + (size_t)ch * 16;
-                    *(u32x4*)(Cp + g) = *(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a);
-                    if (EPI == VK_EPI_GELU) *(u32x4*)(C2p + g) = *(const u32x4 VK_LDS*)(uintptr_t)(img2 + a);
+                    if (AT && EPI == VK_EPI_F32) __builtin_nontemporal_store(*(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a), (u32x4*)(Cp + g));      // weight-gradient slab: read once, by the tail launch
+                    else *(u32x4*)(Cp + g) = *(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a);
+                    // gelu'(u) is read again only by the backward pass: stored non-temporally so that it does not push the activation beside
+                    // it -- the next GEMM's A operand -- out of the Infinity Cache
+                    if (EPI == VK_EPI_GELU) __builtin_nontemporal_store(*(const u32x4 VK_LDS*)(uintptr_t)(img2 + a), (u32x4*)(C2p + g));
                 }
             }
         }

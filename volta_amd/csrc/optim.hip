@@ -167,9 +167,10 @@ __global__ __launch_bounds__(256) void side_tail_kernel(const TailJobs t) {
         const size_t n4 = (size_t)J.n >> 2;
         const size_t i = (size_t)blk * 256 + threadIdx.x;
         if (i < n4) {
-            f32x4 a = *(const f32x4*)(J.src + i * 4);
+            // the slabs are read once, here: non-temporal loads keep them from displacing the backward chain's tensors in the Infinity Cache
+            f32x4 a = __builtin_nontemporal_load((const f32x4*)(J.src + i * 4));
             for (int s = 1; s < J.count; ++s) {
-                const f32x4 b = *(const f32x4*)(J.src + (size_t)s * J.stride + i * 4);
+                const f32x4 b = __builtin_nontemporal_load((const f32x4*)(J.src + (size_t)s * J.stride + i * 4));
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a[r] += b[r];
             }
