@@ -46,11 +46,12 @@ __device__ __forceinline__ void stage_offsets(uint32_t (&off)[2], int ld, int ex
     }
 }
 
+template <int AUX = 0>      // AUX 2 = non-temporal: the operand's last use (a weight gradient's saved activation), kept from displacing live tensors in the Infinity Cache
 __device__ __forceinline__ void stage_half(__amdgpu_buffer_rsrc_t rs, uint32_t slot, const uint32_t (&off)[2], uint32_t add, int wave) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const uint32_t dst = slot + (i * 512 + wave * 64) * 16;       // wave-uniform; hardware adds lane * 16
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (VK_LDS void*)(uintptr_t)dst, 16, off[i] + add, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (VK_LDS void*)(uintptr_t)dst, 16, off[i] + add, 0, 0, AUX);
     }
 }
 
@@ -307,7 +308,7 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
         const bool live = p < np;
         const uint32_t sa = lds0 + (uint32_t)slot * 2u * HT;
         stage_half(rsA, sa, offA, live ? (uint32_t)p * kA : OOB, wave);
-        stage_half(rsB, sa + HT, offB, live ? (uint32_t)p * kB : OOB, wave);
+        stage_half<(AT && BT) ? 2 : 0>(rsB, sa + HT, offB, live ? (uint32_t)p * kB : OOB, wave);
     };
 
     f32x4 acc[8][TJ];

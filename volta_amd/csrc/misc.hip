@@ -11,7 +11,7 @@ __global__ void set_seed_kernel(uint64_t* p, uint64_t v) { *p = v; }
 __global__ void cast_f32_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n) {
     const size_t n8 = n >> 3;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (size_t)gridDim.x * blockDim.x) {
-        const f32x4 a = *(const f32x4*)(src + i * 8), b = *(const f32x4*)(src + i * 8 + 4);
+        const f32x4 a = __builtin_nontemporal_load((const f32x4*)(src + i * 8)), b = __builtin_nontemporal_load((const f32x4*)(src + i * 8 + 4));
         *(u32x4*)(dst + i * 8) = u32x4{pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3])};
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 7)) dst[n8 * 8 + threadIdx.x] = f2bf(src[n8 * 8 + threadIdx.x]);

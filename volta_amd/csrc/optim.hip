@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256) void sqnorm_chunks_kernel(const float* g, size
         const float* p = g + chunk * 1024;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const f32x4 v = *(const f32x4*)(p + (k * 64 + lane) * 4);
+            const f32x4 v = __builtin_nontemporal_load((const f32x4*)(p + (k * 64 + lane) * 4));
             s += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
         }
     }
@@ -93,8 +93,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(vk_adamw_args a) {
     const float lr = a.lr * a.cls_lr_mult[cls], wd = a.cls_wd[cls];
     const float gs = a.grad_scale * (a.clip ? a.clip[1] : 1.f);
     const size_t i = chunk * 1024 + threadIdx.x * 4;
-    const f32x4 g = *(const f32x4*)(a.g + i);
-    f32x4 p = *(f32x4*)(a.p + i), m = *(f32x4*)(a.m + i), v = *(f32x4*)(a.v + i);
+    // one pass over 7 GB that nothing reads again before the next step's optimizer: non-temporal, so that a step pipelined under the next
+    // forward does not sweep that forward's activations out of the Infinity Cache; the bf16 copies are what the forward reads
+    const f32x4 g = __builtin_nontemporal_load((const f32x4*)(a.g + i));
+    f32x4 p = __builtin_nontemporal_load((const f32x4*)(a.p + i)), m = __builtin_nontemporal_load((const f32x4*)(a.m + i)), v = __builtin_nontemporal_load((const f32x4*)(a.v + i));
     const float step = lr * a.step_mult;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -104,7 +106,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(vk_adamw_args a) {
         p[r] = p[r] - step * (m[r] / (sqrtf(v[r]) + a.eps));
         if (wd > 0.f) p[r] = p[r] - lr * wd * p[r];
     }
-    *(f32x4*)(a.p + i) = p; *(f32x4*)(a.m + i) = m; *(f32x4*)(a.v + i) = v;
+    __builtin_nontemporal_store(p, (f32x4*)(a.p + i)); __builtin_nontemporal_store(m, (f32x4*)(a.m + i)); __builtin_nontemporal_store(v, (f32x4*)(a.v + i));
     if (a.shadow) *(u32x2*)((uint16_t*)a.shadow + i) = u32x2{pack2bf(p[0], p[1]), pack2bf(p[2], p[3])};
 }
 
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(256) void side_tail_kernel(const TailJobs t) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a[r] += b[r];
             }
-            *(f32x4*)(J.dst + i * 4) = a;
+            __builtin_nontemporal_store(a, (f32x4*)(J.dst + i * 4));      // the gradient arena: next read by the norm / optimizer, a step's length away
         }
         if (blk == 0 && threadIdx.x < (J.n & 3)) {
             const size_t k = n4 * 4 + threadIdx.x;
