@@ -314,7 +314,7 @@ def main():
     # is the wall time of the issuing loop, which the bounded HIP queues throttle to the GPU's pace once they are full -- it approaches
     # ms_per_step by construction and says nothing about host cost; this figure does.
     host_work = []
-    for _ in range(3):
+    for _ in range(0 if a.no_kernel_timing else 3):       # (profiling runs count launches per step: no extra steps there)
         fence()
         th = time.perf_counter()
         step()
@@ -322,7 +322,7 @@ def main():
     fence()
     gflop = GFLOP_PER_PAIR.get((a.config, a.seq_len, a.regions))
     out, ms, pairs_s = result_line(a, world, elapsed, t_issue, {
-        "host_work_ms_per_step": min(host_work) * 1e3,
+        "host_work_ms_per_step": min(host_work) * 1e3 if host_work else None,
         "host_note": "host_work = one step issued into an empty queue (the host's own cost); host_issue = wall time of the issuing loop, throttled "
                      "by queue back-pressure to the GPU's pace",
         **({"rehearsal": "all ranks share cuda:0 over gloo: timings are meaningless"} if shared else {}),
