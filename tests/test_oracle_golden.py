@@ -165,6 +165,45 @@ def test_adamw_matches_torch_adam_when_no_decay():
     np.testing.assert_allclose(p2.numpy(), (p3 * (1 - lr * 0.01)).numpy(), atol=1e-7)
 
 
+def test_adamw_matches_torch_optim_adam_step_by_step():
+    """The same identity against the real torch.optim.Adam (not a restated formula): with eps_t = eps / sqrt(1 - b2^t) set before every
+    step, torch's update  lr / bc1 * m / (sqrt(v) / sqrt(bc2) + eps_t)  IS pytorch-transformers'  lr sqrt(bc2) / bc1 * m / (sqrt(v) + eps)."""
+    g = torch.Generator().manual_seed(1)
+    p0 = torch.randn(4096, generator=g)
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-6
+    q = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.Adam([q], lr=lr, betas=(b1, b2), eps=eps)
+    p, m, v = p0.clone(), torch.zeros(4096), torch.zeros(4096)
+    for t in range(1, 21):
+        gr = torch.randn(4096, generator=g) * (1.0 + 0.1 * t)
+        R.adamw_step(p, gr, m, v, t, lr, b1, b2, eps, 0.0, True)
+        opt.param_groups[0]["eps"] = eps / np.sqrt(1.0 - b2 ** t)
+        q.grad = gr.double()
+        opt.step()
+        np.testing.assert_allclose(p.numpy(), q.detach().float().numpy(), atol=2e-6, rtol=0)
+    st = opt.state[q]
+    np.testing.assert_allclose(m.numpy(), st["exp_avg"].float().numpy(), atol=1e-6)
+    np.testing.assert_allclose(v.numpy(), st["exp_avg_sq"].float().numpy(), atol=1e-6)
+
+
+def test_warmup_linear_schedule_matches_the_successor_package():
+    """pytorch-transformers 1.1.0 (absent here) was renamed `transformers`; its WarmupLinearSchedule lives on there as
+    get_linear_schedule_with_warmup.  The image has transformers: the oracle's multiplier and the product's WarmupLinearSchedule are
+    held against it step by step (same lineage, later version -- the strongest pin available for this piece of SURVEY.md 8a-17)."""
+    transformers = pytest.importorskip("transformers")
+    from volta_amd.optimization import WarmupLinearSchedule
+    for warm, total in ((10, 100), (0, 50), (100, 100000), (7, 8)):
+        mk = lambda: torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=1.0)
+        o_ref, o_own = mk(), mk()
+        ref = transformers.get_linear_schedule_with_warmup(o_ref, num_warmup_steps=warm, num_training_steps=total)
+        own = WarmupLinearSchedule(o_own, warmup_steps=warm, t_total=total)
+        for step in range(0, min(total + 5, 400)):
+            want = o_ref.param_groups[0]["lr"]
+            assert abs(o_own.param_groups[0]["lr"] - want) <= 1e-12, (warm, total, step)
+            assert abs(R.warmup_linear(step, warm, total) - want) <= 1e-12, (warm, total, step)
+            o_ref.step(); ref.step(); o_own.step(); own.step()
+
+
 def test_warmup_linear_schedule():
     assert R.warmup_linear(0, 10, 100) == 0.0
     assert R.warmup_linear(5, 10, 100) == 0.5
