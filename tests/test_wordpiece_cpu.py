@@ -1,8 +1,9 @@
-"""Native BERT tokenizer (csrc/wordpiece.cpp) against an independent implementation present in the image: the `tokenizers` package's
-BertWordPieceTokenizer (the Rust library behind Hugging Face's BertTokenizer).  The reference's own tokenizer, pytorch-transformers 1.1, is absent
-(parity unpinned against IT; both descend from Devlin et al.'s tokenization.py).  Known difference kept out of the random texts: the Rust normalizer
-strips accents BEFORE lower-casing, BERT's original (and pytorch-transformers) after -- only characters whose lower-case form carries a new
-combining mark (U+0130) tell the two apart; and context-sensitive lower-casing of a final capital sigma."""
+"""Native BERT tokenizer (csrc/wordpiece.cpp) against two implementations present in the image.  The reference's own tokenizer, pytorch-transformers
+1.1's BertTokenizer, is absent; its Python classes live on as transformers.models.bert.tokenization_bert_legacy (BasicTokenizer + WordpieceTokenizer,
+same lineage, later version): the closest witness, compared on every text incl. the order-sensitive ones.  The `tokenizers` package's
+BertWordPieceTokenizer (Rust) is an independent second check; its normalizer strips accents BEFORE lower-casing where BERT's original (and the Python
+lineage) does it after -- only characters whose lower-case form carries a new combining mark (U+0130) tell the two apart -- and it has no final-sigma
+rule, so those characters are kept out of the texts compared with it."""
 import os
 import sys
 
@@ -85,6 +86,62 @@ def test_random_texts_match_the_rust_tokenizer(toks):
     for i, t in enumerate(texts[:257]):
         want = mine.encode(t)[:12]
         assert int(counts[i]) == len(want) and ids[i, :len(want)].tolist() == want and not ids[i, len(want):].any()
+
+
+def _random_texts(n, seed, with_order_sensitive=False):
+    rng = np.random.default_rng(seed)
+    accents = ["é", "è", "ï", "ü", "ñ", "ç", "É", "Ö", "́", "̈", "ß", "Ł", "ø"] + (["İ", "Σ", "ς"] if with_order_sensitive else [])
+    spaces = [" ", "  ", "\t", "\n", "\r\n", "\u00a0", "\u2003", "\u3000"]
+    junk = ["\x00", "\x07", "\x7f", "\u200b", "\u00ad", "\ufffd", "\ufeff"]
+    texts = []
+    for _ in range(n):
+        parts = []
+        for _ in range(int(rng.integers(0, 14))):
+            r = rng.random()
+            if r < 0.55:
+                w = WORDS[int(rng.integers(len(WORDS)))]
+                if rng.random() < 0.3:
+                    w = w.upper() if rng.random() < 0.5 else w.capitalize()
+                if rng.random() < 0.35:
+                    w += PIECES[int(rng.integers(len(PIECES)))][2:]
+                if rng.random() < 0.15:
+                    k = int(rng.integers(0, len(w) + 1))
+                    w = w[:k] + accents[int(rng.integers(len(accents)))] + w[k:]
+                if rng.random() < 0.05:
+                    k = int(rng.integers(0, len(w) + 1))
+                    w = w[:k] + junk[int(rng.integers(len(junk)))] + w[k:]
+                parts.append(w)
+            elif r < 0.75:
+                parts.append(PUNCT[int(rng.integers(len(PUNCT)))])
+            elif r < 0.85:
+                parts.append("".join(chr(int(c)) for c in rng.integers(97, 123, int(rng.integers(1, 12)))))
+            else:
+                parts.append("")
+            if rng.random() < 0.8:
+                parts.append(spaces[int(rng.integers(len(spaces)))])
+        texts.append("".join(parts))
+    return texts
+
+
+def test_random_texts_match_the_python_lineage_of_the_reference_tokenizer(toks):
+    """The reference tokenises with pytorch-transformers 1.1's BertTokenizer = BasicTokenizer + WordpieceTokenizer in Python.  That package is absent, but
+    its classes live on, under the package's later name, as transformers.models.bert.tokenization_bert_legacy (same code path: clean -> CJK spacing ->
+    whitespace split -> lower -> NFD + strip Mn -> punctuation split -> greedy longest-match pieces).  Same lineage, later version: the closest witness the image
+    holds, and it covers what the Rust comparison had to leave out -- the dotted capital I and the capital sigma, where lower-casing BEFORE accent
+    stripping (this lineage, and csrc/wordpiece.cpp) and after it differ."""
+    legacy = pytest.importorskip("transformers.models.bert.tokenization_bert_legacy")
+    mine, _, vocab = toks
+    index = {t: i for i, t in enumerate(vocab)}
+    basic = legacy.BasicTokenizer(do_lower_case=True)
+    pieces = legacy.WordpieceTokenizer(vocab=index, unk_token="[UNK]")
+
+    def ref_ids(text):
+        return [index[p] for w in basic.tokenize(text) for p in pieces.tokenize(w)]
+    fixed = ["İstanbul dog", "ΣΟΦΟΣ the ΟΔΟΣ", "Σ", "dogΣ cat", "A dog running on the grass.", "Cafés!  naïve\tdog", "中国x dogs", "x" * 100, "x" * 101,
+             "dog\u200b cat\x00 run\ufffd", "2019's photo-of (man)", "ÜBER Straße", ""]
+    texts = fixed + _random_texts(3000, 1, with_order_sensitive=True)
+    bad = [(t, mine.encode(t), ref_ids(t)) for t in texts if mine.encode(t) != ref_ids(t)]
+    assert not bad, (len(bad), bad[:3])
 
 
 def test_unusable_vocabularies_and_bytes(toks, tmp_path):

@@ -105,6 +105,18 @@ void fold(uint32_t c, std::vector<uint32_t>& out) {
     out.push_back(c);
 }
 
+// str.lower()'s one context rule (CPython handle_capital_sigma; the reference lower-cases each whitespace-separated token with it): U+03A3 at
+// position k of the token [b, e) takes the final form U+03C2 when the nearest character before it that is not case-ignorable is cased and the
+// nearest one after it that is not case-ignorable is not (or there is none).
+bool final_sigma(const std::vector<uint32_t>& cp, size_t b, size_t e, size_t k) {
+    size_t j = k;
+    while (j > b && in_ranges(CASE_IGNORABLE, N_CASE_IGNORABLE, cp[j - 1])) --j;
+    if (j == b || !in_ranges(CASED, N_CASED, cp[j - 1])) return false;
+    j = k + 1;
+    while (j < e && in_ranges(CASE_IGNORABLE, N_CASE_IGNORABLE, cp[j])) ++j;
+    return j == e || !in_ranges(CASED, N_CASED, cp[j]);
+}
+
 }  // namespace
 
 struct vk_wordpiece {
@@ -159,7 +171,10 @@ struct vk_wordpiece {
             while (j < cp.size() && cp[j] != ' ') ++j;
             if (j == i) break;
             w.clear();
-            if (lowercase) for (size_t k = i; k < j; ++k) fold(cp[k], w);
+            if (lowercase) for (size_t k = i; k < j; ++k) {
+                if (cp[k] == 0x3A3 && final_sigma(cp, i, j, k)) w.push_back(0x3C2);
+                else fold(cp[k], w);
+            }
             else w.assign(cp.begin() + i, cp.begin() + j);
             // split at punctuation: every punctuation character is a word of its own
             size_t b = 0;
