@@ -1105,12 +1105,13 @@ class StepEngine:
                 key = gW.data_ptr()
                 per_w.setdefault(key, (gW, gB, Mo, No, []))[4].append((dY, X, self.st[m].M, lda, ldb))
             jobs += list(per_w.values())
-        # K-chunk length: ~5120 rows, halved (down to ~1280) while the whole group still yields fewer than ~200 tiles of 256 x 256 -- the
-        # attention sub-layers' group ([768, 768] and [2304, 768] outputs) is 108 tiles of 150 K-steps at 5120, i.e. 42 % of the CUs
-        # busy for 127 us; more, shorter chunks fill the chip (the extra slabs cost the tail launch a few microseconds)
+        # K-chunk length: ~5120 rows, halved (down to ~1280) while the whole group still yields fewer than 130 tiles of 256 x 256 (half the
+        # CUs) -- the attention sub-layers' group ([768, 768] and [2304, 768] outputs) is 108 tiles of 150 K-steps at 5120, i.e. 42 % of the
+        # CUs busy for 127 us; more, shorter chunks fill the chip, but every halving doubles the slab traffic: past half the chip it costs more
+        # than the idle CUs (a threshold of 200 cut the text-only groups into 288 tiles of 40 K-steps: +0.08 ms per step)
         chunk_rows = 5120.0
         tiles = lambda cr: sum(-(-Mo // 256) * -(-No // 256) * sum(max(1, int(round(rows / cr))) for _, _, rows, _, _ in srcs) for _, _, Mo, No, srcs in jobs)
-        while chunk_rows > 1280 and tiles(chunk_rows) < 200:
+        while chunk_rows > 1280 and tiles(chunk_rows) < 130:     # (round 3 sweep, profiles/r03_experiments.md: 130 = half the CUs; 200 cut the text-only groups once more, +0.08 ms)
             chunk_rows /= 2
         probs, reduces = [], []
         for gW, gB, Mo, No, srcs in jobs:
