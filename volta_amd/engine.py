@@ -1008,10 +1008,11 @@ class StepEngine:
                 ab.dq[m], ab.dk[m], ab.dv[m], ab.ldg[m] = base, base + 2 * Ha[m], base + 4 * Ha[m], 3 * Ha[m]
             self.k(ab)
             b.append((L.OP_ATTN_BWD, 0, 0, 0, aa, ab, None))
-        self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dqkv[m], wqkv(m, "shadow"), dxn[m], self.st[m].M, Hm[m], 3 * Ha[m], 3 * Ha[m], Hm[m], Hm[m], R=dz[m], ldr=Hm[m]) for m in ms])
-        # all weight gradients of the sub-layer in ONE grouped launch (more workgroups per CU)
+        # all weight gradients of the sub-layer in ONE grouped launch (more workgroups per CU), listed in front of the Q|K|V
+        # dgrad: they need dqkv, not its product, and start beside that GEMM instead of beside the next sub-layer's LayerNorm backward
         self._wgrad(b, ms, shared, [lambda m: (dd[m], ctx[m], self.G(names[m]["o"] + ".weight"), self.G(names[m]["o"] + ".bias"), Hm[m], Ha[m], Hm[m], Ha[m]),
                                     lambda m: (dqkv[m], x_in[m], wqkv(m, "grad"), bqkv(m, "grad"), 3 * Ha[m], Hm[m], 3 * Ha[m], Hm[m])])
+        self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dqkv[m], wqkv(m, "shadow"), dxn[m], self.st[m].M, Hm[m], 3 * Ha[m], 3 * Ha[m], Hm[m], Hm[m], R=dz[m], ldr=Hm[m]) for m in ms])
         return b
 
     def _ln_pair(self, ops, kind, jobs):
@@ -1085,9 +1086,12 @@ class StepEngine:
             du[m] = self.tmp("du%d_%d%s" % (m, par, wtag), (self.st[m].M, Im[m]))
         self._ln_pair(b, L.OP_LN_BWD, lnb)
         self.gemm(b, L.NN, L.EPI_MULR, [self.prob(dd[m], self.W(names[m]["down"] + ".weight"), du[m], self.st[m].M, Im[m], Hm[m], Hm[m], Im[m], Im[m], R=gp[m], ldr=Im[m]) for m in ms])
-        self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(du[m], self.W(names[m]["up"] + ".weight"), dxn[m], self.st[m].M, Hm[m], Im[m], Im[m], Hm[m], Hm[m], R=dz[m], ldr=Hm[m]) for m in ms])
+        # The weight gradients need dd, h, du and x_in: everything but the LAST dgrad's output.  Their side-stream block is listed in front of that
+        # dgrad, so that it starts beside a GEMM (two MFMA-bound launches share the chip without loss) instead of beside the LayerNorm backward
+        # that follows, which it used to keep waiting for CUs (profiles/r03_experiments.md: 17.00 / 16.94 -> 16.52 / 16.54 ms per step).
         self._wgrad(b, ms, shared, [lambda m: (dd[m], h[m], self.G(names[m]["down"] + ".weight"), self.G(names[m]["down"] + ".bias"), Hm[m], Im[m], Hm[m], Im[m]),
                                     lambda m: (du[m], x_in[m], self.G(names[m]["up"] + ".weight"), self.G(names[m]["up"] + ".bias"), Im[m], Hm[m], Im[m], Hm[m])])
+        self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(du[m], self.W(names[m]["up"] + ".weight"), dxn[m], self.st[m].M, Hm[m], Im[m], Im[m], Hm[m], Hm[m], R=dz[m], ldr=Hm[m]) for m in ms])
         return b
 
     def _wgrad(self, b, ms, shared, specs):
