@@ -285,7 +285,7 @@ def main():
         lm, img, nsp = net(*args)
         loss = lm + img + nsp
         loss.backward()
-        clip_grad_norm_(model.parameters(), 5.0, defer_to_optimizer=True)
+        clip_grad_norm_(model.parameters(), 5.0)
         opt.step()
         sched.step()
         opt.zero_grad()

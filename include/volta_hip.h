@@ -84,6 +84,20 @@ typedef struct vk_gemm_problem {
     void* ws;
     int32_t* cnt;
     int32_t part, nparts;
+    /* Row-block hand-off between two launches of ONE stream (NULL / 0 = off; see VK_GEMM_SOFT_START below).  A row block is 256 rows.
+       sig: int32 per row block of C.  Every tile adds 1 to sig[its row block] once its part of C is in memory: C leaves the epilogue as
+            write-through stores, every wave drains them, one lane adds (agent scope).  After the launch sig[rb] = column tiles per row block.
+       dep / dep_need: int32 per row block of A.  A tile asks for its A rows only after dep[its row block] >= dep_need (one lane polls,
+            the workgroup waits at a barrier; the A rows are then read with cache-bypassing loads).  Everything ELSE the problem reads
+            (B, bias, R) must be complete when the launch is enqueued.
+       err: raised to 1 when a poll gives up (> 2^20 rounds: a mis-planned dependency; the tile then runs on whatever is there), or NULL.
+       The counters are the caller's: zero before the PRODUCER is enqueued, read-only for the consumer.  NT / NN, geometries 258 / 259,
+       whole tiles (M % 256 == 0; a signalling problem: geometry 258, N % 256 == 0, C rows 128-byte aligned), no dyn, no split. */
+    int32_t* sig;
+    const int32_t* dep;
+    int32_t* err;
+    int32_t dep_need;
+    int32_t reserved_;
 } vk_gemm_problem;
 #define VK_GEMM_MAX_GROUP 32
 /* One launch for up to VK_GEMM_MAX_GROUP independent problems of the same layout / epilogue. */
@@ -94,6 +108,13 @@ int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* probs, int 
  * workgroups per CU, csrc/gemm4w.hip); 262 (128 x 128 tiles, 4 waves, ring of 6 K-steps: launches too small for 256-row tiles).  A per-call argument, no library state: re-entrant. */
 #define VK_GEMM_PERSISTENT 0x1000
 #define VK_GEMM_ONE_TILE_PER_WG 0x2000
+/* Soft boundary: enqueue the launch WITHOUT the stream-order barrier (the AQL packet's barrier bit is cleared, hipExtAnyOrderLaunch -- honoured
+ * on gfx950, tools/micro/anyorder.hip): its workgroups take CUs as the launch in front of it frees them, and its tiles start as the row
+ * blocks they read are signalled (`dep`), instead of after that launch's last tile, its end-of-kernel write-back and the dispatch ramp.
+ * The caller guarantees: every input is complete at enqueue time or guarded by `dep`; nothing the launch writes is read or written by a
+ * launch that may still run.  The next launch WITHOUT this flag waits for all earlier ones, as always.  (The workgroups of one queue are
+ * dispatched in enqueue order -- tools/micro/dispatch_order.hip -- so a polling workgroup never holds a CU that a producer still needs.) */
+#define VK_GEMM_SOFT_START 0x4000
 int vk_gemm_grouped_ex(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, int geometry, vk_stream_t s);
 /* Workspace of a split accumulation (see vk_gemm_problem::ws): bytes of `ws` for one product [M, N] cut into `nparts` parts under tile
  * geometry 258 / 259; *tiles receives the number of int32 counters `cnt` needs.  Host-side arithmetic, no device work. */
@@ -427,6 +448,10 @@ int vk_sum_slabs_f32(float* dst, const float* src, int64_t slab_stride, int nsla
 /* Same with a bf16 destination and a device-side row count: rows = min(*dyn_rows, n / row_len) rows of row_len. */
 int vk_sum_slabs_bf16(void* dst, const float* src, int64_t slab_stride, int nslabs, int64_t n, const int32_t* dyn_rows, int row_len, vk_stream_t s);
 int vk_memset_async(void* p, int value, int64_t bytes, vk_stream_t s);
+/* Test / measurement aid, no counterpart in the reference: `nwg` (<= 256) workgroups that own a CU each (all 160 KiB of its LDS) for
+ * `usec` (<= 100000) microseconds -- the uneven load under which the row-block hand-offs are tested, and the stand-in for a
+ * communication kernel's CU footprint (tools/comm_footprint.py). */
+int vk_hold_cus(int nwg, int usec, vk_stream_t s);
 /* The tail of a sub-layer's weight-gradient block in ONE launch: every split-K slab sum (kind 0, as vk_sum_slabs_f32) and every
  * deferred LayerNorm dgamma / dbeta column reduction (kind 1, as vk_ln_bwd_finalize) of the sub-layer.  The reference has no
  * counterpart (autograd accumulates each of these tensors with its own kernels); njobs <= VK_TAIL_MAX_JOBS. */

@@ -145,3 +145,65 @@ def test_zero1_shards_world2_and_world3_gloo():
     for world in (2, 3):
         for cap in (1, 4 * 3000, 1 << 30):
             mp.spawn(_worker_zero1, args=(world, _free_port(), cap), nprocs=world, join=True)
+
+
+class _StubArena:
+    """What AdamW's checkpoint code touches of a ParamArena (no GPU): one parameter per slot range."""
+
+    def __init__(self, params, slot):
+        self.params = {"p%d" % i: p for i, p in enumerate(params)}
+        self.offset = {"p%d" % i: i * slot for i in range(len(params))}
+        self.shape = {"p%d" % i: tuple(p.shape) for i, p in enumerate(params)}
+        self.opt_pending = None
+
+    def sync_optimizer(self):
+        pass
+
+
+def _worker_zero1_checkpoint(rank, world, port):
+    """The reference saves the optimizer on ONE rank (`if default_gpu:` around optimizer.state_dict(), volta/train_utils.py:295-316):
+    state_dict() must not enter a collective.  Under "zero1" every rank calls consolidate_state_dict() first; without it state_dict()
+    raises (on whichever rank calls it) instead of hanging or saving stale foreign shards."""
+    import types
+    import pytest
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from volta_amd.parallel import BucketReducer, plan_buckets, SLOT
+    from volta_amd.optimization import AdamW
+    nslots = 6
+    total = nslots * SLOT
+    params = [torch.nn.Parameter(torch.zeros(SLOT)) for _ in range(nslots)]
+    opt = AdamW(params, lr=1e-3)
+    flat = torch.ones(total)
+    red = BucketReducer(flat, mode="zero1")
+    red.begin_step()
+    spans = {"p%d" % i: (i * SLOT, SLOT) for i in range(nslots)}
+    for stage, ranges in plan_buckets(spans, {n: 0 for n in spans}, 1, 1 << 30, pad_to=SLOT, total=total):
+        red.reduce(ranges)
+    red.finish()
+    model = types.SimpleNamespace(_ddp=types.SimpleNamespace(reducer=red))
+    m, v = torch.zeros(total), torch.zeros(total)
+    for lo, hi in red.owned():                      # the sharded step touched this rank's shards only
+        m[lo:hi] = rank + 1.0
+        v[lo:hi] = 10.0 * (rank + 1)
+    opt._fused = dict(model=model, arena=_StubArena(params, SLOT), m=m, v=v, step=4, zero1_layout=tuple(red.sharded))
+    with pytest.raises(RuntimeError, match="consolidate_state_dict"):
+        opt.state_dict()                            # every rank, no collective entered: nobody hangs
+    opt.consolidate_state_dict()                    # collective: every rank
+    if rank == 0:                                   # the reference's `if default_gpu:` save
+        sd = opt.state_dict()
+        got = torch.cat([sd["state"][i]["exp_avg"].reshape(-1) for i in range(nslots)])
+        assert bool((got > 0).all()), "every shard's moments reached the saving rank"
+        owners = set(got.unique().tolist())
+        assert owners == {float(r + 1) for r in range(world)}, owners
+        assert all(int(sd["state"][i]["step"]) == 4 for i in range(nslots))
+    dist.barrier()
+    opt._fused["step"] = 5                          # another step invalidates the gathered copy
+    with pytest.raises(RuntimeError, match="consolidate_state_dict"):
+        opt.state_dict()
+    dist.destroy_process_group()
+
+
+def test_zero1_state_dict_is_collective_free_rank0_only_save_gloo():
+    mp.spawn(_worker_zero1_checkpoint, args=(2, _free_port()), nprocs=2, join=True)

@@ -72,10 +72,11 @@ def _worker(rank, world, port, shared_gpu=False):
             opt = AdamW(m2.parameters(), lr=1e-3, weight_decay=0.01)
             for step in range(3):
                 sum(ddp(*args_of(200 + 10 * step + rank))).sum().backward()
-                clip_grad_norm_(m2.parameters(), 0.5, defer_to_optimizer=True)      # small enough to be active
+                clip_grad_norm_(m2.parameters(), 0.5)      # small enough to be active; the plain call of train_concap.py:307
                 opt.step()
                 opt.zero_grad()
             torch.cuda.synchronize()
+            opt.consolidate_state_dict()           # collective (a no-op for the unsharded wrapper); state_dict() itself never is
             sd = opt.state_dict()["state"]
             runs[mode] = (m2._arena.master.clone(), m2._arena.shadow.clone(), torch.cat([sd[i]["exp_avg"].reshape(-1) for i in sorted(sd)]),
                           torch.cat([sd[i]["exp_avg_sq"].reshape(-1) for i in sorted(sd)]), ddp.reducer.bytes_on_wire)

@@ -250,3 +250,110 @@ def test_split_accumulation_rejects_incomplete_groups():
         ops.gemm_grouped(L.NT, L.EPI_BF16, parts[:1], geometry=258)      # a part is missing
     with pytest.raises(RuntimeError):
         ops.gemm_grouped(L.NT, L.EPI_BF16, parts, geometry=128)          # not a 256-row geometry
+
+
+# ---- soft boundaries: a GEMM enqueued without the stream-order barrier, its tiles guarded by row-block counters of the GEMM in front of it
+def _ffn_pair(L, ops, rows, I, H, seed, layout=None, soft=True):
+    """FFN-up + GELU -> FFN-down as the engine lists them: problems per stream of `rows`, plus the counters of the hand-off."""
+    layout = L.NT if layout is None else layout
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    nrb = [M // 256 for M in rows]
+    cnt = torch.zeros(1 + 32 * len(rows) + sum(nrb), device="cuda", dtype=torch.int32)
+    up, down, keep, outs, sigs = [], [], [], [], []
+    cur = 32
+    for M in rows:
+        x, W1, W2 = rnd((M, H), g, 0.5), rnd((I, H), g, 0.05), rnd((H, I), g, 0.05)
+        b1, b2 = torch.randn(I, generator=g, device="cuda") * 0.1, torch.randn(H, generator=g, device="cuda") * 0.1
+        h = torch.full((M, I), float("nan"), device="cuda", dtype=torch.bfloat16)
+        gp = torch.full((M, I), float("nan"), device="cuda", dtype=torch.bfloat16)
+        d = torch.full((M, H), float("nan"), device="cuda", dtype=torch.bfloat16)
+        pu = ops.gemm_problem(x, W1, h, L.NT, M, I, H, bias=b1, C2=gp)
+        pd = ops.gemm_problem(h, W2, d, L.NT, M, H, I, bias=b2)
+        if soft:
+            sig = cnt.data_ptr() + 4 * cur
+            pu.sig, pu.err = sig, cnt.data_ptr()
+            pd.dep, pd.err, pd.dep_need = sig, cnt.data_ptr(), I // 256
+            sigs.append(cnt[cur:cur + M // 256])
+            cur += (M // 256 + 31) // 32 * 32
+        up.append(pu); down.append(pd); keep += [x, W1, W2, b1, b2]; outs.append((h, gp, d))
+    return up, down, cnt, sigs, outs, keep
+
+
+def _run_pair(L, ops, up, down, cnt, soft):
+    if soft:
+        cnt[1:].zero_()
+    ops.gemm_grouped(L.NT, L.EPI_GELU, up, geometry=258)
+    ops.gemm_grouped(L.NT, L.EPI_BF16, down, geometry=259 | (L.GEMM_SOFT_START if soft else 0))
+
+
+@pytest.mark.parametrize("rows", [(5120, 9472), (5120,), (256,), (1024, 256)])
+def test_soft_boundary_ffn_pair_equals_the_fenced_pair(rows):
+    """The consumer's tiles start while the producer still runs and read row blocks as they are signalled: same bits as the two launches
+    behind the stream-order barrier, on every one of 20 back-to-back runs (whoever finishes first), counters at their column-tile count,
+    error word clear."""
+    L, ops = _mods()
+    I, H = 3072, 768
+    up, down, cnt, sigs, outs, keep = _ffn_pair(L, ops, rows, I, H, seed=11, soft=True)
+    upf, downf, _, _, outsf, keepf = _ffn_pair(L, ops, rows, I, H, seed=11, soft=False)
+    _run_pair(L, ops, upf, downf, None, False)
+    torch.cuda.synchronize()
+    for (h, gp, d), (hf, gpf, df) in zip(outs, outsf):
+        assert torch.isfinite(df.float()).all()
+    for rep in range(20):
+        for h, gp, d in outs:
+            d.fill_(float("nan")); h.fill_(float("nan"))
+        _run_pair(L, ops, up, down, cnt, True)
+        torch.cuda.synchronize()
+        assert int(cnt[0]) == 0, "a guarded tile gave up waiting"
+        for sig in sigs:
+            assert bool((sig == I // 256).all()), sig.tolist()
+        for (h, gp, d), (hf, gpf, df) in zip(outs, outsf):
+            assert torch.equal(h, hf) and torch.equal(gp, gpf), "producer output differs (rep %d)" % rep
+            assert torch.equal(d, df), "consumer read a row block before it was complete (rep %d): %d elements differ" % (rep, int((d != df).sum()))
+
+
+def test_soft_boundary_under_uneven_load():
+    """A second stream holds 64 CUs while the pair runs (late producer workgroups, consumer workgroups that start long before their row
+    blocks exist): still the fenced pair's bits, nobody hangs, no poll gives up."""
+    L, ops = _mods()
+    rows, I, H = (5120, 9472), 3072, 768
+    up, down, cnt, sigs, outs, keep = _ffn_pair(L, ops, rows, I, H, seed=5, soft=True)
+    upf, downf, _, _, outsf, keepf = _ffn_pair(L, ops, rows, I, H, seed=5, soft=False)
+    _run_pair(L, ops, upf, downf, None, False)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for rep, (nwg, usec) in enumerate([(64, 150), (128, 60), (200, 100), (64, 400), (255, 30)]):
+        for h, gp, d in outs:
+            d.fill_(float("nan")); h.fill_(float("nan"))
+        cnt[1:].zero_()
+        torch.cuda.synchronize()
+        L.check(L.lib.vk_hold_cus(nwg, usec, ctypes_ptr(side)))
+        ops.gemm_grouped(L.NT, L.EPI_GELU, up, geometry=258)
+        ops.gemm_grouped(L.NT, L.EPI_BF16, down, geometry=259 | L.GEMM_SOFT_START)
+        L.check(L.lib.vk_hold_cus(nwg, usec // 2, ctypes_ptr(side)))
+        torch.cuda.synchronize()
+        assert int(cnt[0]) == 0, "a guarded tile gave up waiting"
+        for (h, gp, d), (hf, gpf, df) in zip(outs, outsf):
+            assert torch.equal(h, hf) and torch.equal(d, df), "rep %d (%d CUs held for %d us)" % (rep, nwg, usec)
+
+
+def ctypes_ptr(stream):
+    import ctypes
+    return ctypes.c_void_p(stream.cuda_stream)
+
+
+def test_soft_boundary_rejects_what_it_cannot_guard():
+    L, ops = _mods()
+    up, down, cnt, sigs, outs, keep = _ffn_pair(L, ops, (512,), 512, 768, seed=1, soft=True)
+    with pytest.raises(RuntimeError):
+        ops.gemm_grouped(L.NT, L.EPI_GELU, up, geometry=128)                       # not a 256-row geometry
+    with pytest.raises(RuntimeError):
+        ops.gemm_grouped(L.NT, L.EPI_GELU, up, geometry=259)                       # 192-wide producer tiles: partial lines
+    with pytest.raises(RuntimeError):
+        ops.gemm_grouped(L.NT, L.EPI_BF16, down, geometry=128 | L.GEMM_SOFT_START)
+    down[0].dep_need = 0
+    with pytest.raises(RuntimeError):
+        ops.gemm_grouped(L.NT, L.EPI_BF16, down, geometry=259 | L.GEMM_SOFT_START)
+    upr, downr, cntr, _, _, keepr = _ffn_pair(L, ops, (300,), 512, 768, seed=1, soft=True)      # ragged rows
+    with pytest.raises(RuntimeError):
+        ops.gemm_grouped(L.NT, L.EPI_GELU, upr, geometry=258)

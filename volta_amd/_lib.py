@@ -10,7 +10,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # VK_LIB=study loads the measurement build (tools/ only: ablation switches, geometry overrides, the 4-phase study kernel); any other
 # name loads libvolta_hip_<name>.so, a second build of the same sources for an A/B in one box session (tools/ab_bench.sh)
 LIB_PATH = os.path.join(_HERE, "libvolta_hip_%s.so" % os.environ["VK_LIB"] if os.environ.get("VK_LIB") else "libvolta_hip.so")
-GEMM_PERSISTENT, GEMM_ONE_TILE_PER_WG = 0x1000, 0x2000
+GEMM_PERSISTENT, GEMM_ONE_TILE_PER_WG, GEMM_SOFT_START = 0x1000, 0x2000, 0x4000
 
 
 class VoltaHipError(RuntimeError):
@@ -47,7 +47,8 @@ def rng_cfg(seed_ptr, site):
 class GemmProblem(C.Structure):
     _fields_ = [("A", c_p), ("B", c_p), ("C", c_p), ("C2", c_p), ("bias", c_p), ("R", c_p), ("bias_grad", c_p),
                 ("dyn", c_p), ("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32), ("ldc", i32),
-                ("ldr", i32), ("n_store", i32), ("ws", c_p), ("cnt", c_p), ("part", i32), ("nparts", i32)]
+                ("ldr", i32), ("n_store", i32), ("ws", c_p), ("cnt", c_p), ("part", i32), ("nparts", i32),
+                ("sig", c_p), ("dep", c_p), ("err", c_p), ("dep_need", i32), ("reserved_", i32)]
 
 
 class GemmFp8Problem(C.Structure):
@@ -243,6 +244,7 @@ _sig("vk_axpy_f32", C.c_int, c_p, c_p, C.c_float, C.c_int64, c_p)
 _sig("vk_sum_slabs_f32", C.c_int, c_p, c_p, C.c_int64, C.c_int, C.c_int64, c_p)
 _sig("vk_sum_slabs_bf16", C.c_int, c_p, c_p, C.c_int64, C.c_int, C.c_int64, c_p, C.c_int, c_p)
 _sig("vk_memset_async", C.c_int, c_p, C.c_int, C.c_int64, c_p)
+_sig("vk_hold_cus", C.c_int, C.c_int, C.c_int, c_p)
 _sig("vk_side_tail", C.c_int, C.POINTER(TailJob), C.c_int, c_p)
 _sig("vk_run_ops", C.c_int, C.POINTER(Op), C.c_int, c_p)
 _sig("vk_run_ops_timed", C.c_int, C.POINTER(Op), C.c_int, c_p, C.POINTER(C.c_float))
@@ -262,7 +264,7 @@ EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_c
            "vk_xent_bwd", "vk_kl_fwd", "vk_kl_bwd", "vk_loss_finalize", "vk_pool_mul_fwd", "vk_pool_mul_bwd",
            "vk_pool_fuse_fwd", "vk_pool_fuse_bwd", "vk_text_end_rows", "vk_vlbert_obj_ids", "vk_vlbert_positions", "vk_vis_loss_fwd", "vk_vis_loss_bwd", "vk_nce_negatives",
            "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_grad_norm_clip_masked", "vk_grad_sqnorm_chunks", "vk_grad_norm_from_chunks", "vk_adamw_step",
-           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_side_tail", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_join_from", "vk_side_enable", "vk_concap_batch",
+           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_hold_cus", "vk_side_tail", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_join_from", "vk_side_enable", "vk_concap_batch",
            "vk_lmdb_open", "vk_lmdb_close", "vk_lmdb_entries", "vk_lmdb_first", "vk_lmdb_next", "vk_lmdb_get", "vk_concap_record_decode", "vk_concap_records_decode", "vk_b64_decode",
            "vk_wordpiece_open", "vk_wordpiece_close", "vk_wordpiece_vocab_size", "vk_wordpiece_token_id", "vk_wordpiece_encode", "vk_wordpiece_encode_batch"]
 

@@ -226,7 +226,7 @@ extern "C" int vk_gemm_fp8_grouped(int epilogue, const vk_gemm_fp8_problem* prob
     for (int i = 0; i < nprob; ++i) t256 += ((probs[i].p.M + 255) / 256) * ((probs[i].p.N + 255) / 256);
     int edge = geometry ? geometry : (t256 >= 160 ? 256 : 128);
     if (edge != 128 && edge != 256) return set_error("vk_gemm_fp8_grouped: geometry %d (128 or 256)", geometry);
-    KGroup8 g;
+    KGroup8 g{};          // zero: no split accumulation, no row-block hand-off
     g.nprob = nprob;
     g.plain_order = any_dyn ? 1 : 0;
     int total = 0;

@@ -268,14 +268,17 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
             if (!q.ws || !q.cnt || q.part < 0 || q.part >= q.nparts) return set_error("vk_gemm_grouped: split accumulation needs ws, cnt and 0 <= part < nparts");
             if (q.dyn) return set_error("vk_gemm_grouped: split accumulation does not take a device-side row count");
             if (((uintptr_t)q.ws & 15)) return set_error("vk_gemm_grouped: ws must be 16-byte aligned");
-            int seen = 0;
+            if (q.nparts > 30) return set_error("vk_gemm_grouped: a split accumulation has at most 30 parts (got %d)", q.nparts);
+            int seen = 0, count = 0;
             for (int j = 0; j < nprob; ++j)
                 if (probs[j].ws == q.ws && probs[j].nparts > 1) {
                     if (probs[j].M != q.M || probs[j].N != q.N || probs[j].C != q.C || probs[j].cnt != q.cnt || probs[j].nparts != q.nparts)
                         return set_error("vk_gemm_grouped: the parts of one split accumulation must agree in M, N, C, cnt and nparts");
+                    if (probs[j].part < 0 || probs[j].part >= q.nparts) return set_error("vk_gemm_grouped: split accumulation part %d out of range [0, %d)", probs[j].part, q.nparts);
                     seen |= 1 << probs[j].part;
+                    ++count;               // a duplicated part beside a complete set would hand the tile nparts + 1 tickets
                 }
-            if (q.nparts > 30 || seen != (1 << q.nparts) - 1) return set_error("vk_gemm_grouped: a split accumulation needs each of its %d parts exactly once in the launch", q.nparts);
+            if (count != q.nparts || seen != (1 << q.nparts) - 1) return set_error("vk_gemm_grouped: a split accumulation needs each of its %d parts exactly once in the launch", q.nparts);
         }
     }
 #ifdef VK_STUDY
@@ -295,6 +298,9 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
     // yield >= g_min_tiles256 workgroups, and of the two widths the one with less work on the busiest CU:
     // rounds(tiles / 256 CUs) x tile width.  N = 768 -> 4 column tiles of 192 instead of 3 of 256 (228 instead of
     // 171 workgroups for the ViLBERT row counts: one round of smaller tiles), N = 2304 -> 12 instead of 9.
+    const bool soft = (geometry & VK_GEMM_SOFT_START) != 0;
+    bool any_handoff = false;
+    for (int i = 0; i < nprob; ++i) any_handoff |= probs[i].sig != nullptr || probs[i].dep != nullptr;
     const int walk = geometry & (VK_GEMM_PERSISTENT | VK_GEMM_ONE_TILE_PER_WG);
     int edge = geometry & 0xFFF;
     if (edge == 0) {
@@ -321,9 +327,22 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
         }
     }
     if (edge != 256 && edge != 258 && edge != 259 && edge != 260 && edge != 261 && edge != 262) edge = 128;
+    if ((any_handoff || soft) && (layout == VK_TN || any_dyn || any_split || (edge != 258 && edge != 259)))
+        return set_error("vk_gemm_grouped: row-block hand-off (sig / dep / VK_GEMM_SOFT_START) runs on the NT / NN layouts with the 256-row geometries 258 / 259, without dyn or split accumulation (layout %d, geometry %d)", layout, geometry & 0xFFF);
+    if (any_handoff) {
+        const int bn_ = edge == 259 ? 192 : 256;
+        for (int i = 0; i < nprob; ++i) {
+            const vk_gemm_problem& q = probs[i];
+            if (!q.sig && !q.dep) continue;
+            // whole tiles only: the handed-off rows leave the epilogue as full-line write-through stores (no ragged path), and a row block is 256 rows
+            if (q.sig && ((q.M & 255) || (q.N % bn_) || f32out || ((q.ldc * 2) & 127) || ((uintptr_t)q.C & 127) || (edge == 259)))
+                return set_error("vk_gemm_grouped: a signalling problem needs M %% 256 == 0, N %% 256 == 0 under geometry 258, a bf16 C with 128-byte aligned rows (M %d N %d ldc %d)", q.M, q.N, q.ldc);
+            if (q.dep && (q.dep_need <= 0 || (q.M & 255))) return set_error("vk_gemm_grouped: a guarded problem needs dep_need > 0 and M %% 256 == 0");
+        }
+    }
     if (any_split && edge != 258 && edge != 259) return set_error("vk_gemm_grouped: split accumulation runs on the 256 x 256 / 256 x 192 geometries (258 / 259), got %d", geometry & 0xFFF);
     const int bm = (edge == 128 || edge == 262) ? 128 : 256, bn = edge == 259 ? 192 : (edge == 260 || edge == 261 || edge == 262) ? 128 : bm;
-    KGroup g;
+    KGroup g{};
     g.nprob = nprob;
     g.stagger = (g_stagger & 0xFF) | ((g_debug & 0xFF) << 8);
     // Problems with a device-side row count (heads on labelled rows) keep only their first few row tiles alive; the
@@ -337,6 +356,7 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
         k.R = (const char*)q.R; k.bias_grad = q.bias_grad; k.dyn = q.dyn; k.C8 = nullptr; k.c8_mul = 0.f; k.ldc8 = 0;
         k.M = q.M; k.N = q.N; k.K = q.K; k.lda = q.lda; k.ldb = q.ldb; k.ldc = q.ldc; k.ldr = q.ldr; k.n_store = q.n_store;
         k.ws = (char*)q.ws; k.cnt = q.cnt; k.part = q.part; k.nparts = q.nparts;
+        k.sig = q.sig; k.dep = q.dep; k.err = q.err; k.dep_need = q.dep_need;
         const int ncols = (f32out && q.n_store > q.N) ? q.n_store : q.N;
         k.tiles_n = (ncols + bn - 1) / bn;
         k.tile_start = total;
@@ -352,7 +372,7 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
         if (walk == VK_GEMM_PERSISTENT) persistent = persistent && true;
         else if (walk == VK_GEMM_ONE_TILE_PER_WG) persistent = false;
         else persistent = persistent && g_persistent && total > NUM_CU;
-        return launch_gemm256(layout, epilogue, g, total, s, edge == 258 ? 4 : edge == 259 ? 3 : edge == 260 ? 2 : 0, persistent);
+        return launch_gemm256(layout, epilogue, g, total, s, edge == 258 ? 4 : edge == 259 ? 3 : edge == 260 ? 2 : 0, persistent, soft);
     }
     {
         const bool reg = g_regstage_override >= 0 ? g_regstage_override != 0 : layout != VK_NT;

@@ -19,6 +19,7 @@
 // Stages past the end of K are issued with an out-of-range offset (the buffer bounds check turns them into
 // zero fills without memory traffic) so that the vmcnt arithmetic is the same in every iteration.
 #include "gemm_common.h"
+#include <hip/hip_ext.h>
 #include <type_traits>
 
 namespace vk {
@@ -264,6 +265,10 @@ __device__ __forceinline__ bf16x8 frag_strip(uint32_t strip, int r0, int lane) {
     return *(const bf16x8 VK_LDS*)(uintptr_t)(strip + r * 64 + (((lane >> 4) ^ kswz(r)) << 4));
 }
 
+#ifdef VK_STUDY
+__device__ unsigned long long* g_kstamps = nullptr;      // tools/stamp_soft.py: start / end s_memrealtime of every workgroup of the one-tile kernel
+#endif
+
 // TJ = 16-column tiles per wave along N: 4 -> 256 x 256 tile, 3 -> 256 x 192 (N = 768 / 2304 split into 4 / 12 column
 // tiles instead of 3 / 9: 171 -> 228 and 513 -> 684 workgroups for the ViLBERT shapes, i.e. fuller rounds of smaller tiles).
 template <bool AT, bool BT, int EPI, int TJ>
@@ -278,6 +283,9 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
     const int wr = wave >> 2, wc = wave & 3;
 
     const int bid = (g.stagger & GROUP_PLAIN_ORDER) ? (int)blockIdx.x : xcd_remap(blockIdx.x, gridDim.x);
+#ifdef VK_STUDY
+    if (g_kstamps && tid == 0) g_kstamps[blockIdx.x * 4] = __builtin_amdgcn_s_memrealtime();
+#endif
     int pi = 0;
 #pragma unroll
     for (int i = 1; i < VK_GEMM_MAX_GROUP; ++i)
@@ -304,12 +312,18 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
     strip_offsets<BT>(offB, P.ldb, n0, BN, tid);
     const uint32_t kA = AT ? 64u * (uint32_t)P.lda : 64u, kB = BT ? 64u * (uint32_t)P.ldb : 64u;     // bytes per 32-deep K-step
     const int np = (K + 31) / 32;
+    const bool guarded = !AT && P.dep != nullptr;          // A rows handed over by an earlier launch that may still be running (soft boundary)
     auto stage = [&](int p, int slot) {
         const bool live = p < np;
         const uint32_t sa = lds0 + (uint32_t)slot * 2u * HT;
-        stage_half(rsA, sa, offA, live ? (uint32_t)p * kA : OOB, wave);
+        if (guarded) stage_half<AUX_SC1>(rsA, sa, offA, live ? (uint32_t)p * kA : OOB, wave);
+        else stage_half(rsA, sa, offA, live ? (uint32_t)p * kA : OOB, wave);
         stage_half<(AT && BT) ? 2 : 0>(rsB, sa + HT, offB, live ? (uint32_t)p * kB : OOB, wave);
     };
+    if (guarded) soft_wait(P.dep, tm, P.dep_need, P.err);
+#ifdef VK_STUDY
+    if (g_kstamps && tid == 0) g_kstamps[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 
     f32x4 acc[8][TJ];
 #pragma unroll
@@ -365,6 +379,10 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
         __syncthreads();           // the ticket word lies in wave 0's staging region
     }
     gemm_epilogue<AT, EPI, 8, TJ>(P, acc, accb, do_bias_grad, m0 + wr * 128, n0 + wc * WN, M, lane, lds0 + (uint32_t)wave * 16384u);
+    if (!AT && P.sig) soft_signal(P.sig, tm);
+#ifdef VK_STUDY
+    if (g_kstamps && tid == 0) g_kstamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -391,6 +409,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int
     const int wr = wave >> 2, wc = wave & 3;
 
     int pi, m0, n0, np;
+    bool guarded;
     __amdgpu_buffer_rsrc_t rsA, rsB;
     uint32_t offA[2], offB[2], kA, kB;
     auto setup = [&](int v) {
@@ -412,16 +431,19 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int
         strip_offsets<BT>(offB, P.ldb, n0, BN, tid);
         kA = AT ? 64u * (uint32_t)P.lda : 64u; kB = BT ? 64u * (uint32_t)P.ldb : 64u;
         np = (K + 31) / 32;
+        guarded = P.dep != nullptr;
     };
     auto stage = [&](int p, int slot) {
         const bool live = p < np;
         const uint32_t sa = lds0 + (uint32_t)slot * 2u * HT;
-        stage_half(rsA, sa, offA, live ? (uint32_t)p * kA : OOB, wave);
+        if (guarded) stage_half<AUX_SC1>(rsA, sa, offA, live ? (uint32_t)p * kA : OOB, wave);
+        else stage_half(rsA, sa, offA, live ? (uint32_t)p * kA : OOB, wave);
         stage_half(rsB, sa + HT, offB, live ? (uint32_t)p * kB : OOB, wave);
     };
 
     int v = blockIdx.x;
     setup(v);
+    if (guarded) soft_wait(g.p[pi].dep, m0 >> 8, g.p[pi].dep_need, g.p[pi].err);
     stage(0, 0); stage(1, 1); stage(2, 2);
     for (;;) {
         f32x4 acc[8][TJ];
@@ -467,16 +489,22 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int
         const int cpi = pi, cm0 = m0, cn0 = n0;
         const int nv = v + (int)gridDim.x;
         const bool more = nv < total;
+        bool staged = false;
         if (more) {                                           // next tile's operands first, then this tile's output
             setup(nv);
-            stage(0, 0); stage(1, 1); stage(2, 2);
+            if (!guarded) { stage(0, 0); stage(1, 1); stage(2, 2); staged = true; }      // a guarded tile asks for its rows behind its poll, below
         }
         if (stamping) st[2] = __builtin_amdgcn_s_memrealtime();
         f32x4 accb[8];
         gemm_epilogue<AT, EPI, 8, TJ, (int)EPI_REGION>(g.p[cpi], acc, accb, false, cm0 + wr * 128, cn0 + wc * WN, g.p[cpi].M, lane,
                                                        lds0 + EPI_BASE + (uint32_t)wave * EPI_REGION);
+        if (g.p[cpi].sig) soft_signal(g.p[cpi].sig, cm0 >> 8);
         if (stamping) st[3] = __builtin_amdgcn_s_memrealtime();
         if (!more) break;
+        if (!staged) {
+            soft_wait(g.p[pi].dep, m0 >> 8, g.p[pi].dep_need, g.p[pi].err);
+            stage(0, 0); stage(1, 1); stage(2, 2);
+        }
         v = nv;
     }
 }
@@ -488,7 +516,10 @@ static constexpr unsigned long long* g_stamps = nullptr;
 #endif
 
 template <bool AT, bool BT, int KSPLIT>      // 4 / 3 / 2: K-split kernel with 256 / 192 / 128 columns; 0: 4-phase 256 x 256 (study builds)
-static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s, bool persistent) {
+static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s, bool persistent, bool soft) {
+    // soft: VK_GEMM_SOFT_START -- the dispatch packet goes out without the barrier bit (hipExtAnyOrderLaunch): workgroups start as CUs come
+    // free while earlier launches of the stream still run; what they read is guarded by the problems' `dep` counters
+    const int flags = soft ? hipExtAnyOrderLaunch : 0;
     constexpr int LDS = (KSPLIT ? 10 : 8) * HT;
 #ifdef VK_STUDY
 #define VK_KERNEL_OF(E) (KSPLIT == 2 ? gemm256k_kernel<AT, BT, E, 2> : KSPLIT == 3 ? gemm256k_kernel<AT, BT, E, 3> : KSPLIT == 4 ? gemm256k_kernel<AT, BT, E, 4> : gemm256_kernel<AT, BT, E>)
@@ -501,13 +532,13 @@ static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s, boo
             if (persistent) {                                                                             \
                 auto kp = gemm256p_kernel<AT, BT, E, KSPLIT>;                                             \
                 static const hipError_t attr_p = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); (void)attr_p; \
-                hipLaunchKernelGGL(kp, dim3(total < NUM_CU ? total : NUM_CU), dim3(512), LDS, s, g, total, g_stamps); \
+                hipExtLaunchKernelGGL(kp, dim3(total < NUM_CU ? total : NUM_CU), dim3(512), LDS, s, nullptr, nullptr, flags, g, total, g_stamps); \
                 break;                                                                                    \
             }                                                                                             \
         }                                                                                                 \
         auto k = VK_KERNEL_OF(E);                                                                         \
         static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); (void)attr; /* once per process, thread-safe */ \
-        hipLaunchKernelGGL(k, dim3(total), dim3(512), LDS, s, g);                                         \
+        hipExtLaunchKernelGGL(k, dim3(total), dim3(512), LDS, s, nullptr, nullptr, flags, g);             \
         break;                                                                                            \
     }
     switch (epi) {
@@ -520,19 +551,19 @@ static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s, boo
 }
 
 template <int KSPLIT>
-static int launch_variant(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, bool persistent) {
-    if (layout == VK_NT) return launch_layout<false, false, KSPLIT>(epilogue, g, total, s, persistent);
-    if (layout == VK_NN) return launch_layout<false, true, KSPLIT>(epilogue, g, total, s, persistent);
-    if (layout == VK_TN) return launch_layout<true, true, KSPLIT>(epilogue, g, total, s, false);
+static int launch_variant(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, bool persistent, bool soft) {
+    if (layout == VK_NT) return launch_layout<false, false, KSPLIT>(epilogue, g, total, s, persistent, soft);
+    if (layout == VK_NN) return launch_layout<false, true, KSPLIT>(epilogue, g, total, s, persistent, soft);
+    if (layout == VK_TN) return launch_layout<true, true, KSPLIT>(epilogue, g, total, s, false, false);
     return set_error("vk_gemm_grouped: unknown layout %d", layout);
 }
 
-int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant, bool persistent) {
-    if (variant == 2) return launch_variant<2>(layout, epilogue, g, total, s, false);
-    if (variant == 3) return launch_variant<3>(layout, epilogue, g, total, s, persistent);
-    if (variant == 4) return launch_variant<4>(layout, epilogue, g, total, s, persistent);
+int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant, bool persistent, bool soft) {
+    if (variant == 2) return launch_variant<2>(layout, epilogue, g, total, s, false, soft);
+    if (variant == 3) return launch_variant<3>(layout, epilogue, g, total, s, persistent, soft);
+    if (variant == 4) return launch_variant<4>(layout, epilogue, g, total, s, persistent, soft);
 #ifdef VK_STUDY
-    return launch_variant<0>(layout, epilogue, g, total, s, false);
+    return launch_variant<0>(layout, epilogue, g, total, s, false, false);
 #else
     return set_error("vk_gemm_grouped: geometry variant %d is not part of this build", variant);
 #endif
@@ -542,4 +573,5 @@ int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStre
 
 #ifdef VK_STUDY
 extern "C" void vk_gemm_set_stamp_buffer(void* p) { vk::g_stamps = (unsigned long long*)p; }
+extern "C" int vk_gemm_set_kstamp_buffer(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(vk::g_kstamps), &p, sizeof(p)); }
 #endif

@@ -16,6 +16,7 @@ struct KProb {
     int32_t tiles_n, tile_start;
     char* C8; float c8_mul; int32_t ldc8;      // GELU epilogue (fp8 path): e4m3 copy of C, q = saturate(C * c8_mul); NULL otherwise
     char* ws; int32_t* cnt; int32_t part, nparts;   // split accumulation (vk_gemm_problem): nparts <= 1 = off
+    int32_t* sig; const int32_t* dep; int32_t* err; int32_t dep_need;      // row-block hand-off between launches (vk_gemm_problem::sig / dep)
 };
 constexpr int GROUP_PLAIN_ORDER = 1 << 16;    // KGroup::stagger flag: workgroup i takes tile i (no XCD chunking)
 struct KGroup {
@@ -68,6 +69,43 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // holds element K-1 of the LAST row would count as out of range and read as zero (found with the one-column region-logit head: K = 1 lost
 // the whole last row).  The row is extended to an even element count inside its leading dimension; the extra element is a pad column, which
 // is zero by the ragged-K contract (lda padded to a multiple of 64, pad written as 0) or meets an out-of-range (zero) row of the other operand.
+#ifndef VK_WT_GEMM
+#define VK_WT_GEMM 0
+#endif
+#ifndef VK_WT_SLAB
+#define VK_WT_SLAB 0
+#endif
+// 16-byte write-through (sc1) store: the line goes to the memory side at once and is dropped from the XCD's L2, so it is not among the
+// dirty lines the end-of-kernel release has to write back (MI355X_MICROARCH.md, "stores of each flavour" / boundary row)
+__device__ __forceinline__ void store16_wt(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+
+// ---- row-block hand-off between two launches of one stream (include/volta_hip.h, vk_gemm_problem::sig / dep; VK_GEMM_SOFT_START) ----
+// The form is MI355X_MICROARCH.md's "valid forms" table, third row: the producer's stores of the handed-off bytes are 16-byte write-through
+// (sc1) stores of whole lines, every storing wave drains them (s_waitcnt vmcnt(0)), the workgroup meets at a barrier and ONE lane adds 1 to
+// the row block's counter (agent scope); the consumer polls that counter with sc1 loads from ONE lane, the workgroup meets at a barrier
+// behind the poll, and every load of the handed-off bytes is an sc1 load (the A operand's LDS-DMA loads carry aux = sc1).
+// A poll that does not see its count within ~2^20 rounds (> 0.3 s: a mis-planned dependency) raises *err and lets the tile run on what is
+// there -- a wrong result that the host can see, never a hung queue.
+constexpr int AUX_SC1 = 16;
+__device__ __forceinline__ void soft_wait(const int32_t* dep, int rb, int need, int32_t* err) {
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(dep + rb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1 << 20)) {
+                if (err) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+}
+__device__ __forceinline__ void soft_signal(int32_t* sig, int rb) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave, before the barrier the adding lane passes
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(sig + rb, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 __device__ __forceinline__ int even_up(int K, int ld) { const int e = (K + 1) & ~1; return e < ld ? e : ld; }
 
 template <bool AT, int EPI, int TI, int TJ, int REGION = 16384>       // REGION: bytes of the wave-private LDS staging region
@@ -102,6 +140,7 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
         constexpr int SWZ = POW2 ? (CPR < 8 ? CPR - 1 : 7) : 0; // XOR mask of the chunk swizzle (stays inside the row: 4 chunks for 256 x 128 bf16 tiles)
         static_assert(TIH >= 1 && RPH * PITCH * NIMG <= REGION, "epilogue staging does not fit its region");
         const bool via_lds = lds_region != 0 && ((ldc * ES) & 15) == 0 && (((uintptr_t)Cp | (uintptr_t)C2p) & 15) == 0;
+        const bool wt = P.sig != nullptr;
         const uint32_t img2 = lds_region + RPH * PITCH;
         f32x4 b4[TJ];
         {
@@ -183,11 +222,26 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
                     if ((RPI * CPR < 64 && rr0 >= RPI) || ((RPH % RPI) && row >= RPH)) continue;
                     const uint32_t a = row * PITCH + ((ch ^ (row & SWZ)) << 4);
                     const size_t g = ((size_t)(mrow0 + row) * ldc + (size_t)n_base) * ES + (size_t)ch * 16;
-                    if (AT && EPI == VK_EPI_F32) __builtin_nontemporal_store(*(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a), (u32x4*)(Cp + g));      // weight-gradient slab: read once, by the tail launch
+                    if (AT && EPI == VK_EPI_F32) {
+#if VK_WT_SLAB
+                        store16_wt(Cp + g, *(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a));
+#else
+                        __builtin_nontemporal_store(*(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a), (u32x4*)(Cp + g));      // weight-gradient slab: read once, by the tail launch
+#endif
+                    }
+#if VK_WT_GEMM
+                    else store16_wt(Cp + g, *(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a));
+#else
+                    else if (wt) store16_wt(Cp + g, *(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a));      // handed to the next launch by counter (soft_signal)
                     else *(u32x4*)(Cp + g) = *(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a);
+#endif
                     // gelu'(u) is read again only by the backward pass: stored non-temporally so that it does not push the activation beside
                     // it -- the next GEMM's A operand -- out of the Infinity Cache
+#if VK_WT_GEMM > 1
+                    if (EPI == VK_EPI_GELU) store16_wt(C2p + g, *(const u32x4 VK_LDS*)(uintptr_t)(img2 + a));
+#else
                     if (EPI == VK_EPI_GELU) __builtin_nontemporal_store(*(const u32x4 VK_LDS*)(uintptr_t)(img2 + a), (u32x4*)(C2p + g));
+#endif
                 }
             }
         }
@@ -374,7 +428,7 @@ __device__ __forceinline__ bool split_combine(const KProb& P, int tile, f32x4 (&
 // 256-row tiles, 8 waves, LDS-DMA ring (gemm256.hip).  variant 4 / 3 / 2: K-split kernel with 256 / 192 / 128 columns; 0: the 4-phase
 // study kernel (VK_STUDY builds only).  persistent: one workgroup per CU walks the tile list (NT / NN, no device-side row counts).
 constexpr int NUM_CU = 256;       // MI355X
-int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant, bool persistent);
+int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant, bool persistent, bool soft = false);
 // 4-wave ring kernels (gemm4w.hip): bm = 256: 256 x 128 tiles, 72 KiB LDS, two workgroups per CU; bm = 128: 128 x 128 tiles, ring of 6 K-steps
 int launch_gemm4w(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int bm);
 

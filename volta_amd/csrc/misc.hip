@@ -96,3 +96,25 @@ extern "C" int vk_mfma_peak(const uint32_t* seed64, float* out, int iters, int b
     hipLaunchKernelGGL(vk::mfma_peak_kernel, dim3(blocks), dim3(512), 0, (hipStream_t)stream, seed64, out, iters);
     return vk::check_launch("vk_mfma_peak");
 }
+
+// ---- test / measurement aid: `nwg` workgroups that own a CU each (they declare all 160 KiB of LDS) for `usec` microseconds.  The
+// hand-off tests (tests/test_gemm_gpu.py: soft boundaries under UNEVEN load) and tools/comm_footprint.py run it on a second stream.
+namespace vk {
+__global__ void hold_cus_kernel(unsigned ticks) {
+    extern __shared__ char smem[];
+    if (threadIdx.x == 0) {
+        smem[0] = 1;
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();       // 100 MHz
+        while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+    }
+}
+}  // namespace vk
+
+extern "C" int vk_hold_cus(int nwg, int usec, vk_stream_t stream) {
+    if (nwg <= 0 || usec <= 0) return 0;
+    if (nwg > 256 || usec > 100000) return vk::set_error("vk_hold_cus: at most 256 workgroups for at most 0.1 s (got %d, %d us)", nwg, usec);
+    constexpr int LDS = 160 * 1024;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)vk::hold_cus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); (void)attr;
+    hipLaunchKernelGGL(vk::hold_cus_kernel, dim3(nwg), dim3(64), LDS, (hipStream_t)stream, (unsigned)usec * 100u);
+    return vk::check_launch("vk_hold_cus");
+}

@@ -15,6 +15,7 @@ vv, vt probabilities, text output, vision output; pooled) -- the contract the ma
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -246,6 +247,7 @@ class StepEngine:
         self.attn_map_info = []
         self.task_dropout = float(task_dropout)      # BertForVLTasks(dropout_prob=...): nn.Dropout on the fused pooled vector / region states (encoders.py:1118-1122)
         self.fp8 = bool(fp8)
+        self.soft = os.environ.get("VK_SOFT", "1") != "0"        # soft boundaries between dependent GEMMs (0: every launch behind the stream-order barrier)
         dev = arena.device
         self.dev = dev
         H, Hv = cfg.hidden_size, cfg.v_hidden_size
@@ -350,6 +352,24 @@ class StepEngine:
         cur[0] += _round_up(nbytes, 256)
         cur[1] += tiles.value
         return out
+
+    # ---- soft boundaries (include/volta_hip.h, VK_GEMM_SOFT_START): a GEMM whose A operand is the output of the GEMM launched right before it
+    # is enqueued without the stream-order barrier; its tiles wait for row-block counters that the producer's tiles raise
+    SOFT_ROWS = 1 << 16
+
+    def soft_counters(self, nrb):
+        """nrb int32 counters (one per 256-row block) out of the engine's counter arena, which one fill launch at the head of each command
+        list zeroes; plus the address of the error word a timed-out poll raises."""
+        cnt = self.bufs["soft_cnt"]
+        cur = self._soft_cur
+        assert cur + nrb <= cnt.numel(), "soft-boundary counter arena too small"
+        self._soft_cur = cur + _round_up(nrb, 32)            # a producer's counters on lines of their own
+        self._soft_zero.n[0] = 4 * (self._soft_cur - 32)     # the fill launch at the head of the forward list covers every counter handed out
+        return cnt.data_ptr() + 4 * cur, cnt.data_ptr()
+
+    def soft_error(self):
+        """1 when a guarded tile gave up waiting in some step since the engine was built (host synchronisation: tests and diagnostics)."""
+        return int(self.bufs["soft_cnt"][0].item()) if "soft_cnt" in self.bufs else 0
 
     def _split_launch_done(self, tag):
         self.__dict__.setdefault("_split_cur", {})[tag] = [0, 0]
@@ -456,6 +476,13 @@ class StepEngine:
         cfg, B, H = self.cfg, self.B, self.H
         st = self.st
         f = self.fwd.ops
+        if self.soft:
+            # row-block counters of the soft boundaries: word 0 is the error word (never cleared), the counters start on the next line and
+            # are zeroed by ONE fill launch per step, in front of everything (its length grows as _build hands counters out)
+            self.bufs["soft_cnt"] = torch.zeros(self.SOFT_ROWS, dtype=torch.int32, device=self.dev)
+            self._soft_cur = 32
+            self._soft_zero = self.generic(L.FN_MEMSET, p=(self.bufs["soft_cnt"].data_ptr() + 128,), n=(0, 0))
+            f.append((L.OP_GENERIC, 0, 0, 0, self._soft_zero, None, None))
         # per-step inputs (static staging copies are avoided: the few ops that read them are patched)
         self.masks = [self.buf("mask_t", (B, self.T), torch.float32), self.buf("mask_v", (B, self.Rv), torch.float32)]
         for m, name in ((0, "attention_mask"), (1, "image_attention_mask")):
@@ -1015,6 +1042,16 @@ class StepEngine:
         self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dqkv[m], wqkv(m, "shadow"), dxn[m], self.st[m].M, Hm[m], 3 * Ha[m], 3 * Ha[m], Hm[m], Hm[m], R=dz[m], ldr=Hm[m]) for m in ms])
         return b
 
+    @staticmethod
+    def _soft_pair_ok(shapes):
+        """A producer [M, I, H] -> consumer [M, H, I] pair takes the soft boundary when every tile is whole (256-row blocks, 256-wide producer
+        tiles, 192-wide consumer tiles) and both launches are large enough for the 256-row geometries the hand-off is built on."""
+        if any(M % 256 or I % 256 or H % 192 or H % 64 for M, I, H in shapes):
+            return False
+        t_up = sum((M // 256) * (I // 256) for M, I, H in shapes)
+        t_down = sum((M // 256) * -(-H // 256) for M, I, H in shapes)
+        return t_up >= 160 and t_down >= 160
+
     def _ln_pair(self, ops, kind, jobs):
         """One LayerNorm launch for both streams when their widths agree (the kernels share the launch between two jobs of equal width),
         one launch per stream otherwise."""
@@ -1061,8 +1098,17 @@ class StepEngine:
             self.gemm_fp8(f, L.EPI_GELU, up)
             self.gemm_fp8(f, L.EPI_BF16, specs)
         else:
-            self.gemm(f, L.NT, L.EPI_GELU, [self.prob(x_in[m], self.W(names[m]["up"] + ".weight"), h[m], self.st[m].M, Im[m], Hm[m], Hm[m], Hm[m], Im[m], bias=self.Pm(names[m]["up"] + ".bias"), C2=gp[m]) for m in ms])
-            self.gemm(f, L.NT, L.EPI_BF16, [self.prob(h[m], self.W(names[m]["down"] + ".weight"), d[m], self.st[m].M, Hm[m], Im[m], Im[m], Im[m], Hm[m], bias=self.Pm(names[m]["down"] + ".bias")) for m in ms])
+            up = [self.prob(x_in[m], self.W(names[m]["up"] + ".weight"), h[m], self.st[m].M, Im[m], Hm[m], Hm[m], Hm[m], Im[m], bias=self.Pm(names[m]["up"] + ".bias"), C2=gp[m]) for m in ms]
+            down = [self.prob(h[m], self.W(names[m]["down"] + ".weight"), d[m], self.st[m].M, Hm[m], Im[m], Im[m], Im[m], Hm[m], bias=self.Pm(names[m]["down"] + ".bias")) for m in ms]
+            g_up = g_down = 0
+            if self.soft and self._soft_pair_ok([(self.st[m].M, Im[m], Hm[m]) for m in ms]):
+                # FFN-down starts on the CUs FFN-up's last round leaves idle: row block r of h is handed over by counter (12 column tiles of 256)
+                for m, pu, pd in zip(ms, up, down):
+                    pu.sig, pu.err = self.soft_counters(self.st[m].M // 256)
+                    pd.dep, pd.err, pd.dep_need = pu.sig, pu.err, Im[m] // 256
+                g_up, g_down = 258, 259 | L.GEMM_SOFT_START
+            self.gemm(f, L.NT, L.EPI_GELU, up, geometry=g_up)
+            self.gemm(f, L.NT, L.EPI_BF16, down, geometry=g_down)
         odrop, lnf = {}, []
         for m in ms:
             odrop[m] = self.drop(cfg.hidden_dropout_prob if m == 0 else cfg.v_hidden_dropout_prob)

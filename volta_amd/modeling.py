@@ -21,8 +21,30 @@ from .config import BertConfig
 logger = logging.getLogger(__name__)
 
 
+class ArenaParameters:
+    """What `parameters()` of a volta_amd root model returns: nn.Module's parameter iterator, carrying the model it walks.
+    `clip_grad_norm_(model.parameters(), max_norm)` -- the reference's call, train_concap.py:307 -- reads `vk_model` and takes the whole
+    gradient arena in one pass instead of walking 600 tensors (an explicit hook: no generator-frame introspection)."""
+
+    __slots__ = ("vk_model", "started", "_it")
+
+    def __init__(self, model, it):
+        self.vk_model, self.started, self._it = model, False, it
+
+    def __iter__(self):
+        return self
+
+    def __next__(self):
+        self.started = True
+        return next(self._it)
+
+
 class PreTrainedModel(nn.Module):
     """Base with the helpers the reference's driver touches (volta/utils.py:250-360)."""
+
+    def parameters(self, recurse=True):
+        it = super().parameters(recurse)
+        return ArenaParameters(self, it) if (recurse and getattr(self, "_vk_is_model", False)) else it
 
     config_class = BertConfig
     base_model_prefix = "bert"
@@ -385,6 +407,8 @@ class BertForVLPreTraining(PreTrainedModel):
         """Gradient-accumulation bookkeeping shared by the pre-training and the task models.  Parameters of torch-side head
         modules (`_torch_param_prefixes`) get their gradients from autograd (redirected into the arena by a hook)."""
         arena = eng.arena
+        from .optimization import flush_clip
+        flush_clip(arena)                   # a clip coefficient no optimizer step has consumed applies to the gradients it was computed for
         skip = getattr(self, "_torch_param_prefixes", ())
         # frozen parameters (requires_grad False: volta/train_utils.py:250-255) get no .grad, as under autograd; the
         # optimizer and clip_grad_norm_ then leave their arena chunks alone

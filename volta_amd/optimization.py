@@ -12,8 +12,7 @@ import ctypes as C
 import math
 
 import torch
-import inspect
-import os
+import weakref
 
 from torch.optim import Optimizer
 from torch.optim.lr_scheduler import LambdaLR
@@ -98,6 +97,7 @@ class AdamW(Optimizer):
                 cls_of_chunk[c0:c1] = ci
                 spans.append((p, n, c0, c1))
         _check_shared_chunks(arena, {n for _, n, _, _ in spans}, "given to the optimizer")
+        arena._vk_adamw = weakref.ref(self)       # clip_grad_norm_ hands its coefficient to this optimizer's next step (see there)
         self._fused = dict(model=model, arena=arena, classes=classes, base_class=cls_of_chunk, spans=spans, masks={},
                            chunk_class=cls_of_chunk.to(arena.device),
                            m=torch.zeros_like(arena.master), v=torch.zeros_like(arena.master), step=0)
@@ -142,7 +142,13 @@ class AdamW(Optimizer):
         a = L.AdamwArgs()
         a.p, a.g, a.m, a.v = arena.master.data_ptr(), arena.grad.data_ptr(), f["m"].data_ptr(), f["v"].data_ptr()
         a.shadow, a.chunk_class = arena.shadow.data_ptr(), self._chunk_class_for_step().data_ptr()
-        clip = getattr(arena, "pending_clip", None)
+        pend = getattr(arena, "pending_clip", None)
+        clip = None
+        if pend is not None:
+            if pend[1] == self._grad_names():
+                clip = pend[0]                     # the coefficient was computed over exactly the gradients this step consumes: folded into the pass
+            else:
+                flush_clip(arena)                  # another parameter set: applied to its gradients first
         a.clip = clip.data_ptr() if clip is not None else None
         arena.pending_clip = None
         a.n = arena.total
@@ -163,6 +169,10 @@ class AdamW(Optimizer):
             self._step_pipelined(a, arena, clip)
         arena.mark_shadow_fresh()      # the kernel refreshed the bf16 copies itself
         return loss
+
+    def _grad_names(self):
+        """Names of this optimizer's parameters that carry a gradient now (the set a deferred clip coefficient must have been computed over)."""
+        return frozenset(n for p, n, _, _ in self._fused["spans"] if p.grad is not None)
 
     def _zero1_reducer(self):
         """The data-parallel wrapper's reducer when it runs in mode "zero1" and the last backward left this rank with shards to step."""
@@ -240,12 +250,27 @@ class AdamW(Optimizer):
                 out.append((arena.offset[n], numel, tuple(arena.shape[n])))
         return out
 
-    def state_dict(self):
+    def consolidate_state_dict(self):
+        """Data-parallel mode "zero1": every rank holds the moments of its own shards only.  COLLECTIVE -- every rank calls it -- gathers
+        them so that `state_dict()` (which the reference calls on rank 0 alone, volta/train_utils.py:295-316) has the whole state.
+        A no-op without a sharded optimizer, so a driver may call it unconditionally in front of its `if default_gpu:` save."""
         self.synchronize()
+        if self._fused is None:
+            return
+        f = self._fused
         red = self._zero1_reducer()
-        if red is not None and self._fused.get("zero1_layout"):       # every rank's checkpoint holds the whole state
-            red.gather(self._fused["m"], self._fused["zero1_layout"])
-            red.gather(self._fused["v"], self._fused["zero1_layout"])
+        if red is not None and f.get("zero1_layout"):
+            red.gather(f["m"], f["zero1_layout"])
+            red.gather(f["v"], f["zero1_layout"])
+        f["zero1_consolidated_at"] = f["step"]
+
+    def state_dict(self):
+        """Collective-free (the reference's checkpoint flow enters it on one rank).  Under "zero1" the moments must have been gathered by
+        `consolidate_state_dict()` since the last step; otherwise this raises instead of saving other ranks' stale shards."""
+        self.synchronize()
+        if self._fused is not None and self._fused.get("zero1_layout") and self._fused.get("zero1_consolidated_at") != self._fused["step"]:
+            raise RuntimeError("volta_amd.AdamW.state_dict(): the optimizer state is sharded over the data-parallel ranks (mode 'zero1'); "
+                               "call optimizer.consolidate_state_dict() on EVERY rank first, then state_dict() on the saving rank")
         sd = super().state_dict()
         if self._fused is not None and self._fused["step"] > 0:
             f = self._fused
@@ -276,6 +301,8 @@ class AdamW(Optimizer):
         f["step"] = steps.pop()
 
     def zero_grad(self, set_to_none=True):
+        if self._fused is not None:
+            self._fused["arena"].pending_clip = None       # a coefficient nobody consumed dies with the gradients it was computed for
         for g in self.param_groups:
             for p in g["params"]:
                 if set_to_none:
@@ -298,24 +325,41 @@ class WarmupLinearSchedule(LambdaLR):
         return max(0.0, float(self.t_total - step) / float(max(1.0, self.t_total - self.warmup_steps)))
 
 
-def clip_grad_norm_(parameters, max_norm, norm_type=2.0, defer_to_optimizer=False, pre_scale=1.0):
-    """Global L2 norm of the gradients and clipping by max_norm / (norm + 1e-6) when that is < 1.
-    Returns the norm as a 0-dim DEVICE tensor (no host synchronisation).  With `defer_to_optimizer` the
-    coefficient is handed to the next AdamW.step(), which folds it into its single pass over the gradients."""
+def flush_clip(arena):
+    """Apply a clip coefficient that is still waiting for an optimizer step to the gradients it was computed over (and forget it)."""
+    pend = getattr(arena, "pending_clip", None)
+    arena.pending_clip = None
+    if pend is None:
+        return
+    out, names = pend
+    if len(names) == sum(p.grad is not None for _, p in arena.param_list()) == len(arena.param_list()):
+        arena.grad.mul_(out[1])
+    else:
+        for n in names:
+            arena.view(n, "grad").mul_(out[1])
+
+
+def clip_grad_norm_(parameters, max_norm, norm_type=2.0, defer_to_optimizer=None, pre_scale=1.0):
+    """Global L2 norm of the gradients and clipping by max_norm / (norm + 1e-6) when that is < 1 (torch.nn.utils.clip_grad_norm_ as
+    train_concap.py:307 calls it).  Returns the norm as a 0-dim DEVICE tensor (no host synchronisation).
+    Where the scaling happens: when a `volta_amd.AdamW` has been built on this model's parameters, the coefficient is handed to its
+    next `step()`, which folds it into its single pass over the gradients (saves one read + write of the 968 MB gradient arena); it is
+    applied at once instead when no such optimizer exists, when the next step consumes another set of gradients, before the next
+    backward, and by `flush_clip(model.materialize())` for code that reads `.grad` between the two calls.  `defer_to_optimizer=False`
+    forces the eager form, `True` the deferred one."""
     if float(norm_type) != 2.0:
         raise NotImplementedError("only the L2 norm is supported")
     model = None
     whole = False
-    if inspect.isgenerator(parameters) and parameters.gi_code is torch.nn.Module.parameters.__code__ and parameters.gi_frame is not None:
-        # `model.parameters()` of a volta_amd model, not started yet: the whole arena, no need to walk 600 tensors
-        owner = parameters.gi_frame.f_locals.get("self")
-        if getattr(owner, "_vk_is_model", False) and owner.__dict__.get("_arena") is not None:
-            model, arena = owner, owner.materialize()
-            whole = True
+    owner = getattr(parameters, "vk_model", None)          # modeling.ArenaParameters: `model.parameters()` of a volta_amd model
+    if owner is not None and not parameters.started and owner.__dict__.get("_arena") is not None:
+        model, arena = owner, owner.materialize()          # the whole arena, no need to walk 600 tensors
+        whole = True
     if model is None:
         params = [parameters] if isinstance(parameters, torch.Tensor) else list(parameters)
         model, arena = _arena_of(params)
         given = {p.data_ptr() for p in params}
+    flush_clip(arena)                                       # two clips in a row: the first one's scaling is part of what the second measures
     # parameters without a gradient (frozen, or an unused head) are left out, as torch.nn.utils.clip_grad_norm_ does
     plist, gviews = arena.param_list(), arena.grad_views()
     have = []
@@ -362,11 +406,13 @@ def clip_grad_norm_(parameters, max_norm, norm_type=2.0, defer_to_optimizer=Fals
     else:
         L.check(L.lib.vk_grad_sqnorm_chunks(L.ptr(arena.grad), 0, nchunks, L.ptr(mask), L.ptr(sums), L.stream_ptr()))
     L.check(L.lib.vk_grad_norm_from_chunks(L.ptr(sums), npad, pre_scale, float(max_norm), L.ptr(out), L.stream_ptr()))
-    if defer_to_optimizer:
-        arena.pending_clip = out
-    elif mask is None:
-        arena.grad.mul_(out[1])
-    else:
-        for n in have:
-            arena.view(n, "grad").mul_(out[1])
+    names = frozenset(have)
+    if defer_to_optimizer is None:
+        # the reference's plain call: defer when the optimizer that will consume these gradients is ours and steps exactly this set
+        opt = getattr(arena, "_vk_adamw", None)
+        opt = opt() if opt is not None else None
+        defer_to_optimizer = opt is not None and opt._fused is not None and opt._fused["arena"] is arena and opt._grad_names() == names
+    arena.pending_clip = (out, names)
+    if not defer_to_optimizer:
+        flush_clip(arena)
     return out[0]

@@ -286,6 +286,14 @@ class DistributedDataParallel(nn.Module):
             L.check(L.lib.vk_cast_f32_bf16(arena.master.data_ptr() + 4 * lo, arena.shadow.data_ptr() + 2 * lo, hi - lo, L.stream_ptr()))
 
     def run_backward(self, eng):
+        if self.reducer.mode == "zero1":
+            # after a sharded reduction the gradient arena holds the AVERAGE only inside this rank's shards: any consumer other than
+            # volta_amd.AdamW / clip_grad_norm_ (which know the shard layout) would step on un-averaged local gradients and nothing would
+            # gather the parameters -- refuse to start such a step
+            opt = getattr(eng.arena, "_vk_adamw", None)
+            if opt is None or opt() is None:
+                raise RuntimeError("DistributedDataParallel(mode='zero1') shards the gradient reduction for volta_amd.optimization.AdamW: build that "
+                                   "optimizer on the model's parameters (and run one step, or call optimizer._setup()) before the first backward")
         start = 0
         self.reducer.begin_step()
         owner = torch.cuda.current_stream().cuda_stream if self.reducer.cuda else None      # the executor keeps one side stream per caller stream
