@@ -14,6 +14,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # before the HIP runtime starts: one hardware queue per engine stream (volta_amd/streams.py)
+
 import torch
 import torch.distributed as dist
 

@@ -98,6 +98,12 @@ typedef struct vk_gemm_problem {
     int32_t* err;
     int32_t dep_need;
     int32_t reserved_;
+    /* Problem 0 of a launch only (NULL = off): every workgroup of the launch, as it retires, stores *retire_stamp (device uint64) to
+       *retire_flag (device uint64, agent scope).  A vk_gate_wait on ANOTHER stream that polls the flag for that stamp opens when the launch
+       begins to hand CUs back -- how the engine starts a sub-layer's weight-gradient block behind its last dgrad without a stream event,
+       whose cross-queue wake-up latency is not under the program's control (volta_amd/engine.py, profiles/r04_experiments.md). */
+    uint64_t* retire_flag;
+    const uint64_t* retire_stamp;
 } vk_gemm_problem;
 #define VK_GEMM_MAX_GROUP 32
 /* One launch for up to VK_GEMM_MAX_GROUP independent problems of the same layout / epilogue. */
@@ -448,10 +454,35 @@ int vk_sum_slabs_f32(float* dst, const float* src, int64_t slab_stride, int nsla
 /* Same with a bf16 destination and a device-side row count: rows = min(*dyn_rows, n / row_len) rows of row_len. */
 int vk_sum_slabs_bf16(void* dst, const float* src, int64_t slab_stride, int nslabs, int64_t n, const int32_t* dyn_rows, int row_len, vk_stream_t s);
 int vk_memset_async(void* p, int value, int64_t bytes, vk_stream_t s);
-/* Test / measurement aid, no counterpart in the reference: `nwg` (<= 256) workgroups that own a CU each (all 160 KiB of its LDS) for
- * `usec` (<= 100000) microseconds -- the uneven load under which the row-block hand-offs are tested, and the stand-in for a
- * communication kernel's CU footprint (tools/comm_footprint.py). */
-int vk_hold_cus(int nwg, int usec, vk_stream_t s);
+/* No counterpart in the reference: `nwg` (<= 256) one-wave workgroups that stay resident for `usec` (<= 100000) microseconds.
+ * whole_cu != 0: each declares all 160 KiB of a CU's LDS, i.e. owns a CU -- the uneven load under which the row-block hand-offs are
+ * tested and the stream probe of volta_amd/streams.py; whole_cu == 0: a wave slot and nothing else -- a pure DELAY on its stream
+ * (VK_FN_HOLD in a command list: the head of a weight-gradient side block, see volta_amd/engine.py). */
+int vk_hold_cus(int nwg, int usec, int whole_cu, vk_stream_t s);
+/* One wave that stays on stream `s` until *flag == *stamp (device uint64 words, polled with cache-bypassing loads; gives up after
+ * timeout_us, <= 1000000, and raises *err (may be NULL) to 2): everything enqueued on `s` behind it starts when another stream's
+ * launch has stored the stamp (vk_gemm_problem::retire_flag).  The stamp must already hold its value when the gate is ENQUEUED-and-reached:
+ * the engine orders its side stream behind the launch that bumps the epoch word with one event per backward pass (vk_bump_u64). */
+int vk_gate_wait(const uint64_t* flag, const uint64_t* stamp, int timeout_us, int32_t* err, vk_stream_t s);
+/* *word += 1 (device uint64; one lane): the epoch of the gates of one backward pass. */
+int vk_bump_u64(uint64_t* word, vk_stream_t s);
+/* Stream-ordered flag and the gate that waits for it, with the value known to the HOST (a step counter): `vk_store_u64` stores `value` to
+ * *word when stream `s` gets there; `vk_gate_value` holds its stream (one spinning wave) until *flag == want.  Together they order one
+ * stream behind a point of another WITHOUT hipStreamWaitEvent: on gfx950 an AQL barrier packet that sits unsatisfied at the head of a
+ * queue stalls the other queues of its command-processor pipe until it is satisfied (profiles/r04_experiments.md: a reducer stream's
+ * early-enqueued waits cost 2-7 ms on a 16.9 ms step), a running one-wave kernel does not.  volta_amd/parallel.py, volta_amd/optimization.py. */
+int vk_store_u64(uint64_t* word, uint64_t value, vk_stream_t s);
+int vk_gate_value(const uint64_t* flag, uint64_t want, int timeout_us, int32_t* err, vk_stream_t s);
+/* Measurement aid: the CU footprint of a collective library's channel kernels without the library -- `nwg` workgroups of 256 threads copy
+ * `bytes` (multiple of 16) from src to dst and stay resident until `min_usec` have passed since the first of them started (a channel
+ * kernel lives as long as its transfer, at link rate).  stamps: NULL or 2 uint64 {~0, 0} that receive first start / last end in 100 MHz ticks.
+ * Stands where apex's bucket all-reduce would be launched (apex/apex/parallel/distributed.py:425-475) in tools/comm_footprint.py. */
+int vk_comm_standin(const void* src, void* dst, int64_t bytes, int nwg, int min_usec, uint64_t* stamps, vk_stream_t s);
+/* The persistent GEMM launches (one workgroup per CU, geometries 258 / 259 | VK_GEMM_PERSISTENT) leave `n` CUs (0 .. 128) unclaimed from now
+ * on: room for the channel kernels of a collective that runs beside the backward pass.  The ONE piece of process-wide state in the
+ * library -- a launch geometry shared by every stream, set by volta_amd.parallel.DistributedDataParallel (VK_COMM_CUS); returns the
+ * previous value.  n < 0 only queries. */
+int vk_gemm_reserve_cus(int n);
 /* The tail of a sub-layer's weight-gradient block in ONE launch: every split-K slab sum (kind 0, as vk_sum_slabs_f32) and every
  * deferred LayerNorm dgamma / dbeta column reduction (kind 1, as vk_ln_bwd_finalize) of the sub-layer.  The reference has no
  * counterpart (autograd accumulates each of these tensors with its own kernels); njobs <= VK_TAIL_MAX_JOBS. */
@@ -508,7 +539,10 @@ enum {
     VK_FN_NCE_NEG,       /* vk_nce_negatives(drop, n[0], n[1], p[0]) */
     VK_FN_TEXT_END_ROWS, /* vk_text_end_rows(p[0], n[0], n[1], p[1], p[2]) */
     VK_FN_VLBERT_OBJ_IDS, /* vk_vlbert_obj_ids(p[0], p[1], n[0], n[1]) */
-    VK_FN_VLBERT_POSITIONS /* vk_vlbert_positions(p[0], n[0], n[1], n[2], p[1], p[2]) */
+    VK_FN_VLBERT_POSITIONS, /* vk_vlbert_positions(p[0], n[0], n[1], n[2], p[1], p[2]) */
+    VK_FN_HOLD,          /* vk_hold_cus(n[0], n[1], n[2]) */
+    VK_FN_GATE,          /* vk_gate_wait(p[0], p[1], n[0], p[2]) */
+    VK_FN_BUMP           /* vk_bump_u64(p[0]) */
 };                       /* VK_FN_POOL_FWD / VK_FN_POOL_BWD: n[3] = fusion mode (VK_FUSE_*) */
 typedef struct vk_generic_args {   /* positional arguments of the small entry points, see executor.cpp */
     int32_t fn;
@@ -532,6 +566,11 @@ int vk_run_ops_timed(const vk_op* ops, int n, vk_stream_t s, float* ms);
 int vk_side_join(vk_stream_t s);
 /* Make `waiter` (e.g. a communication stream) wait for the side stream that belongs to `owner` (the stream the lists run on). */
 int vk_side_join_from(vk_stream_t owner, vk_stream_t waiter);
+/* The side stream that belongs to `owner` (created on first use; NULL + vk_last_error() on failure): host code that opens further
+   streams beside a command list (communication, a pipelined optimizer) probes them against this one -- HIP streams share a handful of
+   hardware queues, and a stream that shares the side stream's queue serialises the weight gradients behind its own waits
+   (volta_amd/streams.py, profiles/r04_experiments.md). */
+vk_stream_t vk_side_stream(vk_stream_t owner);
 /* 0: run side-stream blocks inline on the caller's stream (serial schedule); 1 (default): concurrently. */
 void vk_side_enable(int on);
 

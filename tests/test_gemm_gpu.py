@@ -327,10 +327,10 @@ def test_soft_boundary_under_uneven_load():
             d.fill_(float("nan")); h.fill_(float("nan"))
         cnt[1:].zero_()
         torch.cuda.synchronize()
-        L.check(L.lib.vk_hold_cus(nwg, usec, ctypes_ptr(side)))
+        L.check(L.lib.vk_hold_cus(nwg, usec, 1, ctypes_ptr(side)))
         ops.gemm_grouped(L.NT, L.EPI_GELU, up, geometry=258)
         ops.gemm_grouped(L.NT, L.EPI_BF16, down, geometry=259 | L.GEMM_SOFT_START)
-        L.check(L.lib.vk_hold_cus(nwg, usec // 2, ctypes_ptr(side)))
+        L.check(L.lib.vk_hold_cus(nwg, usec // 2, 1, ctypes_ptr(side)))
         torch.cuda.synchronize()
         assert int(cnt[0]) == 0, "a guarded tile gave up waiting"
         for (h, gp, d), (hf, gpf, df) in zip(outs, outsf):

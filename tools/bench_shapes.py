@@ -1,4 +1,8 @@
-"""Per-shape A/B of the GEMM tile geometries on the step's GEMM shapes (B = 256), interleaved rounds in one process.
+"""Per-shape A/B of the GEMM tile geometries on the step's GEMM shapes (B = 256), interleaved rounds in one process, next to the
+vendor library's GEMM (torch.matmul -> hipBLASLt / rocBLAS: a YARDSTICK for tools only, never on the product path) under the same
+cold protocol (600 MB flush in front of every timed launch) and hot (10 back-to-back launches).  The vendor column is the bare product
+(no bias, no GELU / residual epilogue; a grouped launch = its problems one after the other), so it is a lower bound for what the fused
+launch could cost with the vendor's kernel.
 usage: bench_shapes.py [geometry codes ...]   (default: 0 = heuristic, 261)"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,6 +12,7 @@ from volta_amd import _lib as L, ops
 
 GEOS = [int(x) for x in sys.argv[1:]] or [0, 261]
 SHAPES = [  # name, layout, epilogue, [(M, N, K), ...]
+    ("image projection fwd", L.NT, L.EPI_BF16, [(9472, 768, 2048)]),
     ("text qkv fwd", L.NT, L.EPI_BF16, [(5120, 2304, 768)]),
     ("text out fwd", L.NT, L.EPI_BF16, [(5120, 768, 768)]),
     ("text ffn-up gelu", L.NT, L.EPI_GELU, [(5120, 3072, 768)]),
@@ -32,7 +37,7 @@ SHAPES = [  # name, layout, epilogue, [(M, N, K), ...]
 def make(layout, epi, shapes):
     g = torch.Generator(device="cuda").manual_seed(0)
     rnd = lambda *s: (torch.randn(*s, generator=g, device="cuda") * 0.5).to(torch.bfloat16)
-    probs, keep, fl = [], [], 0.0
+    probs, keep, fl, vend = [], [], 0.0, []
     for M, N, K in shapes:
         if layout == L.NT:
             A, B = rnd(M, K), rnd(N, K)
@@ -49,7 +54,28 @@ def make(layout, epi, shapes):
         probs.append(ops.gemm_problem(A, B, Cb, layout, M, N, K, bias=bias, C2=C2, R=R, bias_grad=bg))
         keep += [A, B, Cb, C2, R, bias, bg]
         fl += 2.0 * M * N * K
-    return (L.GemmProblem * len(probs))(*probs), keep, fl
+        vend.append((A, B, torch.empty(M, N, device="cuda", dtype=torch.bfloat16)))
+    return (L.GemmProblem * len(probs))(*probs), keep, fl, vend
+
+
+def vendor_call(layout, vend):
+    for A, B, out in vend:
+        if layout == L.NT:
+            torch.matmul(A, B.t(), out=out)
+        elif layout == L.NN:
+            torch.matmul(A, B, out=out)
+        else:
+            torch.matmul(A.t(), B, out=out)
+
+
+def time_vendor(layout, vend, iters):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        vendor_call(layout, vend)
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3
 
 
 def time_one(layout, epi, arr, n, geo, iters=10):
@@ -65,15 +91,22 @@ def time_one(layout, epi, arr, n, geo, iters=10):
 
 # a 600 MB scratch write between rounds pushes operands out of L2 / Infinity Cache: the step runs every GEMM on cold operands
 flush = torch.empty(300 * 1024 * 1024, dtype=torch.bfloat16, device="cuda")
-print("%-28s %s" % ("shape", "  ".join("geo %-4d us (TF/s)" % g for g in GEOS)))
+print("%-28s %s  vendor cold us (TF/s) hot   own-cold / vendor-cold" % ("shape", "  ".join("geo %-4d us (TF/s)" % g for g in GEOS)))
 for name, layout, epi, shapes in SHAPES:
-    arr, keep, fl = make(layout, epi, shapes)
+    arr, keep, fl, vend = make(layout, epi, shapes)
     best = {g: [] for g in GEOS}
+    vbest = []
     for g in GEOS:
         time_one(layout, epi, arr, len(shapes), g, 2)
+    time_vendor(layout, vend, 3)
     for rnd_ in range(5):
         for g in GEOS:
             flush.fill_(1.0)
             best[g].append(time_one(layout, epi, arr, len(shapes), g, 1))
+        flush.fill_(1.0)
+        vbest.append(time_vendor(layout, vend, 1))
     hot = {g: time_one(layout, epi, arr, len(shapes), g, 10) for g in GEOS}
-    print("%-28s %s" % (name, "  ".join("%6.1f (%4.0f) hot %6.1f" % (sorted(best[g])[2], fl / sorted(best[g])[2] / 1e6, hot[g]) for g in GEOS)), flush=True)
+    vhot = time_vendor(layout, vend, 10)
+    vc = sorted(vbest)[2]
+    print("%-28s %s  %6.1f (%4.0f) hot %6.1f   %.2f" % (name, "  ".join("%6.1f (%4.0f) hot %6.1f" % (sorted(best[g])[2], fl / sorted(best[g])[2] / 1e6, hot[g]) for g in GEOS),
+                                                 vc, fl / vc / 1e6, vhot, sorted(best[GEOS[0]])[2] / vc), flush=True)

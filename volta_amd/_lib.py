@@ -48,7 +48,7 @@ class GemmProblem(C.Structure):
     _fields_ = [("A", c_p), ("B", c_p), ("C", c_p), ("C2", c_p), ("bias", c_p), ("R", c_p), ("bias_grad", c_p),
                 ("dyn", c_p), ("M", i32), ("N", i32), ("K", i32), ("lda", i32), ("ldb", i32), ("ldc", i32),
                 ("ldr", i32), ("n_store", i32), ("ws", c_p), ("cnt", c_p), ("part", i32), ("nparts", i32),
-                ("sig", c_p), ("dep", c_p), ("err", c_p), ("dep_need", i32), ("reserved_", i32)]
+                ("sig", c_p), ("dep", c_p), ("err", c_p), ("dep_need", i32), ("reserved_", i32), ("retire_flag", c_p), ("retire_stamp", c_p)]
 
 
 class GemmFp8Problem(C.Structure):
@@ -147,7 +147,7 @@ class Op(C.Structure):
 (FN_CAST, FN_MEMSET, FN_LOC_FWD, FN_LOC_BWD, FN_ADD_DROPOUT, FN_COLSUM, FN_SELECT, FN_GATHER, FN_SCATTER_ADD,
  FN_LOSS_FINAL, FN_POOL_FWD, FN_POOL_BWD, FN_MASK_PREP, FN_MUL, FN_VLBERT_PREP, FN_VLBERT_MASKGRAD, FN_ROWGROUP_SUM,
  FN_RELU_BWD, FN_COPY, FN_SUM_SLABS, FN_SUM_SLABS_BF16, FN_SIDE_TAIL, FN_QUANT_ROWS, FN_CAST_FP8, FN_VIS_LOSS_FWD, FN_VIS_LOSS_BWD,
- FN_NCE_NEG, FN_TEXT_END_ROWS, FN_VLBERT_OBJ_IDS, FN_VLBERT_POSITIONS) = range(1, 31)
+ FN_NCE_NEG, FN_TEXT_END_ROWS, FN_VLBERT_OBJ_IDS, FN_VLBERT_POSITIONS, FN_HOLD, FN_GATE, FN_BUMP) = range(1, 34)
 
 
 class AttnArgs(C.Structure):
@@ -244,7 +244,13 @@ _sig("vk_axpy_f32", C.c_int, c_p, c_p, C.c_float, C.c_int64, c_p)
 _sig("vk_sum_slabs_f32", C.c_int, c_p, c_p, C.c_int64, C.c_int, C.c_int64, c_p)
 _sig("vk_sum_slabs_bf16", C.c_int, c_p, c_p, C.c_int64, C.c_int, C.c_int64, c_p, C.c_int, c_p)
 _sig("vk_memset_async", C.c_int, c_p, C.c_int, C.c_int64, c_p)
-_sig("vk_hold_cus", C.c_int, C.c_int, C.c_int, c_p)
+_sig("vk_hold_cus", C.c_int, C.c_int, C.c_int, C.c_int, c_p)
+_sig("vk_gate_wait", C.c_int, c_p, c_p, C.c_int, c_p, c_p)
+_sig("vk_bump_u64", C.c_int, c_p, c_p)
+_sig("vk_store_u64", C.c_int, c_p, C.c_uint64, c_p)
+_sig("vk_gate_value", C.c_int, c_p, C.c_uint64, C.c_int, c_p, c_p)
+_sig("vk_comm_standin", C.c_int, c_p, c_p, C.c_int64, C.c_int, C.c_int, c_p, c_p)
+_sig("vk_gemm_reserve_cus", C.c_int, C.c_int)
 _sig("vk_side_tail", C.c_int, C.POINTER(TailJob), C.c_int, c_p)
 _sig("vk_run_ops", C.c_int, C.POINTER(Op), C.c_int, c_p)
 _sig("vk_run_ops_timed", C.c_int, C.POINTER(Op), C.c_int, c_p, C.POINTER(C.c_float))
@@ -255,6 +261,7 @@ _sig("vk_concap_batch", C.c_int, C.POINTER(ConcapArgs), c_p)
 _sig("vk_side_join", C.c_int, c_p)
 _sig("vk_side_join_from", C.c_int, c_p, c_p)
 _sig("vk_side_enable", None, C.c_int)
+_sig("vk_side_stream", c_p, c_p)
 
 EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_cast_f32_bf16", "vk_gemm_grouped", "vk_gemm_grouped_ex", "vk_gemm_split_workspace_bytes", "vk_gemm_fp8_grouped", "vk_quant_rows_fp8", "vk_cast_bf16_fp8",
            "vk_ln_fwd", "vk_ln_fwd_pair", "vk_ln_bwd_partial_rows", "vk_ln_bwd", "vk_ln_bwd_pair", "vk_ln_bwd_finalize", "vk_gated_attn_fwd", "vk_gated_attn_bwd",
@@ -264,7 +271,7 @@ EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_c
            "vk_xent_bwd", "vk_kl_fwd", "vk_kl_bwd", "vk_loss_finalize", "vk_pool_mul_fwd", "vk_pool_mul_bwd",
            "vk_pool_fuse_fwd", "vk_pool_fuse_bwd", "vk_text_end_rows", "vk_vlbert_obj_ids", "vk_vlbert_positions", "vk_vis_loss_fwd", "vk_vis_loss_bwd", "vk_nce_negatives",
            "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_grad_norm_clip_masked", "vk_grad_sqnorm_chunks", "vk_grad_norm_from_chunks", "vk_adamw_step",
-           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_hold_cus", "vk_side_tail", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_join_from", "vk_side_enable", "vk_concap_batch",
+           "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_hold_cus", "vk_gate_wait", "vk_bump_u64", "vk_store_u64", "vk_gate_value", "vk_comm_standin", "vk_gemm_reserve_cus", "vk_side_tail", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_join_from", "vk_side_stream", "vk_side_enable", "vk_concap_batch",
            "vk_lmdb_open", "vk_lmdb_close", "vk_lmdb_entries", "vk_lmdb_first", "vk_lmdb_next", "vk_lmdb_get", "vk_concap_record_decode", "vk_concap_records_decode", "vk_b64_decode",
            "vk_wordpiece_open", "vk_wordpiece_close", "vk_wordpiece_vocab_size", "vk_wordpiece_token_id", "vk_wordpiece_encode", "vk_wordpiece_encode_batch"]
 

@@ -12,6 +12,7 @@ static int run_one(const vk_op& o, int i, vk_stream_t s);
 // ---- side streams: one (with its events) per CALLER stream, created on first use and kept for the life of the process.  Two host
 // threads replaying command lists on two streams therefore never share a side stream or an event (re-entrant across streams); the
 // map itself is guarded by a mutex.  vk_side_enable() is the only process-wide switch (profiling: run side blocks inline).
+#include <cstdlib>
 #include <mutex>
 #include <unordered_map>
 namespace {
@@ -40,7 +41,15 @@ Side* side_for(vk_stream_t caller) {
     if (!sp) sp = new Side();
     Side& g = *sp;
     // (default priority: the device's lowest priority for this stream measured no better -- 17.89 / 17.98 against 17.80 / 17.91 ms per step)
-    if (hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking) != hipSuccess) { vk::set_error("side stream: hipStreamCreate failed"); return nullptr; }
+    {
+        // VK_SIDE_PRIORITY=low: the side stream's hardware queue at the device's lowest priority (an experiment knob; see profiles/r04_experiments.md)
+        const char* pr = getenv("VK_SIDE_PRIORITY");
+        int least = 0, greatest = 0;
+        hipError_t e;
+        if (pr && pr[0] == 'l' && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) e = hipStreamCreateWithPriority(&g.stream, hipStreamNonBlocking, least);
+        else e = hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { vk::set_error("side stream: hipStreamCreate failed"); return nullptr; }
+    }
     if (hipEventCreateWithFlags(&g.fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&g.join, hipEventDisableTiming) != hipSuccess) {
         vk::set_error("side stream: hipEventCreate failed");
         return nullptr;
@@ -64,6 +73,11 @@ extern "C" int vk_side_join_from(vk_stream_t owner, vk_stream_t waiter) {
 
 extern "C" int vk_side_join(vk_stream_t s) { return vk_side_join_from(s, s); }
 
+extern "C" vk_stream_t vk_side_stream(vk_stream_t owner) {
+    Side* g = side_for(owner);
+    return g ? (vk_stream_t)g->stream : nullptr;
+}
+
 extern "C" int vk_run_ops(const vk_op* ops, int n, vk_stream_t s) {
     vk_stream_t cur = s;
     Side* g = nullptr;
@@ -75,8 +89,10 @@ extern "C" int vk_run_ops(const vk_op* ops, int n, vk_stream_t s) {
             hipError_t e = hipSuccess;
             switch (o.kind) {
                 case VK_OP_SIDE_BEGIN:
-                    e = hipEventRecord(g->fork, (hipStream_t)s);
-                    if (e == hipSuccess) e = hipStreamWaitEvent(g->stream, g->fork, 0);
+                    if (o.i0 != 1) {          // i0 == 1: no event -- the block opens with a gate (VK_FN_GATE) that a launch of the caller's stream releases
+                        e = hipEventRecord(g->fork, (hipStream_t)s);
+                        if (e == hipSuccess) e = hipStreamWaitEvent(g->stream, g->fork, 0);
+                    }
                     cur = (vk_stream_t)g->stream;
                     break;
                 case VK_OP_SIDE_END:
@@ -95,6 +111,9 @@ extern "C" int vk_run_ops(const vk_op* ops, int n, vk_stream_t s) {
             if (e != hipSuccess) return vk::set_error("vk_run_ops: side-stream control op %d failed at index %d: %s", o.kind, i, hipGetErrorString(e));
             continue;
         }
+        // a gate holds a SIDE stream until a launch of the caller's stream releases it: run inline (serial schedule) it would wait for a launch
+        // that is listed behind it on the same stream
+        if (o.kind == VK_OP_GENERIC && o.a && ((const vk_generic_args*)o.a)->fn == VK_FN_GATE && cur == s) continue;
         int rc = run_one(o, i, cur);
         if (rc != 0) return rc;
     }
@@ -114,7 +133,8 @@ extern "C" int vk_run_ops_timed(const vk_op* ops, int n, vk_stream_t s, float* m
     hipStream_t st = (hipStream_t)s;
     (void)hipEventRecord(ev[0], st);
     for (int i = 0; i < n; ++i) {
-        if (!(ops[i].kind >= VK_OP_SIDE_BEGIN && ops[i].kind <= VK_OP_JOIN)) {     // control ops: nothing to launch, block runs inline
+        const bool gate = ops[i].kind == VK_OP_GENERIC && ops[i].a && ((const vk_generic_args*)ops[i].a)->fn == VK_FN_GATE;
+        if (!(ops[i].kind >= VK_OP_SIDE_BEGIN && ops[i].kind <= VK_OP_JOIN) && !gate) {     // control ops and gates: nothing to launch, block runs inline
             int rc = run_one(ops[i], i, s);
             if (rc != 0) return rc;
         }
@@ -167,6 +187,9 @@ static int run_one(const vk_op& o, int i, vk_stream_t s) {
                     case VK_FN_TEXT_END_ROWS: rc = vk_text_end_rows((const int64_t*)g->p[0], (int)g->n[0], (int)g->n[1], (int32_t*)g->p[1], (int32_t*)g->p[2], s); break;
                     case VK_FN_VLBERT_OBJ_IDS: rc = vk_vlbert_obj_ids((const int32_t*)g->p[0], (int64_t*)g->p[1], (int)g->n[0], (int)g->n[1], s); break;
                     case VK_FN_VLBERT_POSITIONS: rc = vk_vlbert_positions((const int64_t*)g->p[0], (int)g->n[0], (int)g->n[1], (int)g->n[2], (int64_t*)g->p[1], (int64_t*)g->p[2], s); break;
+                    case VK_FN_HOLD: rc = vk_hold_cus((int)g->n[0], (int)g->n[1], (int)g->n[2], s); break;
+                    case VK_FN_GATE: rc = vk_gate_wait((const uint64_t*)g->p[0], (const uint64_t*)g->p[1], (int)g->n[0], (int32_t*)g->p[2], s); break;
+                    case VK_FN_BUMP: rc = vk_bump_u64((uint64_t*)g->p[0], s); break;
                     case VK_FN_MASK_PREP: rc = vk_mask_prep((const int64_t*)g->p[0], (float*)g->p[1], (int)g->n[0], s); break;
                     case VK_FN_MUL: rc = vk_mul_bf16(g->p[0], g->p[1], g->p[2], g->n[0], (const int32_t*)g->p[3], (int)g->n[1], s); break;
                     case VK_FN_VLBERT_PREP: rc = vk_vlbert_prep_fwd((const float*)g->p[0], (int)g->n[3], (const float*)g->p[1], (const float*)g->p[2], g->p[3], (int32_t*)g->p[4], (int)g->n[0], (int)g->n[1], (int)g->n[2], g->drop, s); break;

@@ -195,6 +195,7 @@ void gemm_kernel(const KGroup g) {
     }
 
     gemm_epilogue<AT, EPI, TI, 4>(P, acc, accb, do_bias_grad, m0 + wm * 64 * TM, n0 + wn * 64, M, lane);
+    retire_mark(g);
 }
 
 template <bool AT, bool BT, int WM, int WN, bool REGSTAGE, int TM = 1>
@@ -298,6 +299,8 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
     // yield >= g_min_tiles256 workgroups, and of the two widths the one with less work on the busiest CU:
     // rounds(tiles / 256 CUs) x tile width.  N = 768 -> 4 column tiles of 192 instead of 3 of 256 (228 instead of
     // 171 workgroups for the ViLBERT row counts: one round of smaller tiles), N = 2304 -> 12 instead of 9.
+    if (probs[0].retire_flag && (!probs[0].retire_stamp || ((uintptr_t)probs[0].retire_flag & 7) || ((uintptr_t)probs[0].retire_stamp & 7)))
+        return set_error("vk_gemm_grouped: retire_flag needs retire_stamp, both 8-byte aligned");
     const bool soft = (geometry & VK_GEMM_SOFT_START) != 0;
     bool any_handoff = false;
     for (int i = 0; i < nprob; ++i) any_handoff |= probs[i].sig != nullptr || probs[i].dep != nullptr;
@@ -357,6 +360,7 @@ static int gemm_dispatch(int layout, int epilogue, const vk_gemm_problem* probs,
         k.M = q.M; k.N = q.N; k.K = q.K; k.lda = q.lda; k.ldb = q.ldb; k.ldc = q.ldc; k.ldr = q.ldr; k.n_store = q.n_store;
         k.ws = (char*)q.ws; k.cnt = q.cnt; k.part = q.part; k.nparts = q.nparts;
         k.sig = q.sig; k.dep = q.dep; k.err = q.err; k.dep_need = q.dep_need;
+        if (i == 0) { g.retire_flag = (unsigned long long*)q.retire_flag; g.retire_stamp = (const unsigned long long*)q.retire_stamp; }
         const int ncols = (f32out && q.n_store > q.N) ? q.n_store : q.N;
         k.tiles_n = (ncols + bn - 1) / bn;
         k.tile_start = total;

@@ -21,6 +21,7 @@
 #include "gemm_common.h"
 #include <hip/hip_ext.h>
 #include <type_traits>
+#include <atomic>
 
 namespace vk {
 
@@ -380,6 +381,7 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
     }
     gemm_epilogue<AT, EPI, 8, TJ>(P, acc, accb, do_bias_grad, m0 + wr * 128, n0 + wc * WN, M, lane, lds0 + (uint32_t)wave * 16384u);
     if (!AT && P.sig) soft_signal(P.sig, tm);
+    retire_mark(g);
 #ifdef VK_STUDY
     if (g_kstamps && tid == 0) g_kstamps[blockIdx.x * 4 + 2] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -507,6 +509,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int
         }
         v = nv;
     }
+    retire_mark(g);
 }
 
 #ifdef VK_STUDY
@@ -514,6 +517,9 @@ static unsigned long long* g_stamps = nullptr;          // tools/stamp_gemm.py: 
 #else
 static constexpr unsigned long long* g_stamps = nullptr;
 #endif
+
+// CUs the persistent launches leave unclaimed (vk_gemm_reserve_cus): room for a collective's channel kernels beside the backward pass
+static std::atomic<int> g_reserved_cus{0};
 
 template <bool AT, bool BT, int KSPLIT>      // 4 / 3 / 2: K-split kernel with 256 / 192 / 128 columns; 0: 4-phase 256 x 256 (study builds)
 static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s, bool persistent, bool soft) {
@@ -532,7 +538,8 @@ static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s, boo
             if (persistent) {                                                                             \
                 auto kp = gemm256p_kernel<AT, BT, E, KSPLIT>;                                             \
                 static const hipError_t attr_p = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); (void)attr_p; \
-                hipExtLaunchKernelGGL(kp, dim3(total < NUM_CU ? total : NUM_CU), dim3(512), LDS, s, nullptr, nullptr, flags, g, total, g_stamps); \
+                const int ncu = NUM_CU - g_reserved_cus.load(std::memory_order_relaxed);                  \
+                hipExtLaunchKernelGGL(kp, dim3(total < ncu ? total : ncu), dim3(512), LDS, s, nullptr, nullptr, flags, g, total, g_stamps); \
                 break;                                                                                    \
             }                                                                                             \
         }                                                                                                 \
@@ -570,6 +577,12 @@ int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStre
 }
 
 }  // namespace vk
+
+extern "C" int vk_gemm_reserve_cus(int n) {
+    const int prev = vk::g_reserved_cus.load(std::memory_order_relaxed);
+    if (n >= 0) vk::g_reserved_cus.store(n > 128 ? 128 : (n + 7) & ~7, std::memory_order_relaxed);     // whole multiples of 8: the walk keeps a workgroup on one XCD's chunk
+    return prev;
+}
 
 #ifdef VK_STUDY
 extern "C" void vk_gemm_set_stamp_buffer(void* p) { vk::g_stamps = (unsigned long long*)p; }

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(256, TI == 8 ? 2 : 1) void gemm4w_kernel(const KGro
 
 #undef W4_WAIT_STAGE
     gemm_epilogue<AT, EPI, TI, 4>(P, acc, accb, do_bias_grad, m0 + wr * (BM / 2), n0 + wc * 64, M, lane, lds0 + (uint32_t)wave * 16384u);
+    retire_mark(g);
 }
 
 template <bool AT, bool BT, int TI, int RING>

@@ -22,8 +22,14 @@ constexpr int GROUP_PLAIN_ORDER = 1 << 16;    // KGroup::stagger flag: workgroup
 struct KGroup {
     int32_t nprob;
     int32_t stagger;   // bits 0-7: DMA stagger of the legacy geometries, 8-15: ablation switches (study kernel), 16: GROUP_PLAIN_ORDER
+    unsigned long long* retire_flag;            // vk_gemm_problem::retire_flag of problem 0: every workgroup stores *retire_stamp there as it retires
+    const unsigned long long* retire_stamp;
     KProb p[VK_GEMM_MAX_GROUP];
 };
+// Last statement of a GEMM workgroup: tell a gate on another stream (vk_gate_wait) that this launch has begun to hand CUs back.
+__device__ __forceinline__ void retire_mark(const KGroup& g) {
+    if (g.retire_flag && threadIdx.x == 0) __hip_atomic_store(g.retire_flag, *g.retire_stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // XOR applied to the 16-byte chunk index of a row of a transposed ([k][cols]) image (low 4 bits only)
 __device__ __forceinline__ int tswz(int row) { return ((row & 3) << 1) ^ (((row >> 3) & 1) << 3); }

@@ -97,7 +97,7 @@ extern "C" int vk_mfma_peak(const uint32_t* seed64, float* out, int iters, int b
     return vk::check_launch("vk_mfma_peak");
 }
 
-// ---- test / measurement aid: `nwg` workgroups that own a CU each (they declare all 160 KiB of LDS) for `usec` microseconds.  The
+// ---- `nwg` one-wave workgroups that stay resident for `usec` microseconds; whole_cu: each declares all 160 KiB of LDS, i.e. owns a CU.  The
 // hand-off tests (tests/test_gemm_gpu.py: soft boundaries under UNEVEN load) and tools/comm_footprint.py run it on a second stream.
 namespace vk {
 __global__ void hold_cus_kernel(unsigned ticks) {
@@ -110,11 +110,94 @@ __global__ void hold_cus_kernel(unsigned ticks) {
 }
 }  // namespace vk
 
-extern "C" int vk_hold_cus(int nwg, int usec, vk_stream_t stream) {
+extern "C" int vk_hold_cus(int nwg, int usec, int whole_cu, vk_stream_t stream) {
     if (nwg <= 0 || usec <= 0) return 0;
     if (nwg > 256 || usec > 100000) return vk::set_error("vk_hold_cus: at most 256 workgroups for at most 0.1 s (got %d, %d us)", nwg, usec);
     constexpr int LDS = 160 * 1024;
     static const hipError_t attr = hipFuncSetAttribute((const void*)vk::hold_cus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); (void)attr;
-    hipLaunchKernelGGL(vk::hold_cus_kernel, dim3(nwg), dim3(64), LDS, (hipStream_t)stream, (unsigned)usec * 100u);
+    hipLaunchKernelGGL(vk::hold_cus_kernel, dim3(nwg), dim3(64), whole_cu ? LDS : 64, (hipStream_t)stream, (unsigned)usec * 100u);
     return vk::check_launch("vk_hold_cus");
+}
+
+// ---- measurement aid: the CU footprint of a communication library's channel kernels, without the library (one-GPU boxes cannot run RCCL with
+// more than one rank).  `nwg` workgroups of 256 threads stream `bytes` from src to dst (16-byte non-temporal accesses, each workgroup a
+// contiguous slice) and then stay resident until `min_usec` have passed since the first of them started -- a channel kernel lives as long
+// as its transfer does, at link rate, not at HBM rate.  stamps (optional, 2 x uint64): first start / last end, s_memrealtime (100 MHz).
+namespace vk {
+__global__ __launch_bounds__(256) void comm_standin_kernel(const u32x4* __restrict__ src, u32x4* __restrict__ dst, size_t n16, unsigned min_ticks,
+                                                           unsigned long long* stamps) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    if (stamps && threadIdx.x == 0) atomicMin(stamps, t0);
+    const size_t per = (n16 + gridDim.x - 1) / gridDim.x, lo = per * blockIdx.x, hi = lo + per < n16 ? lo + per : n16;
+    for (size_t i = lo + threadIdx.x; i < hi; i += 256) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
+    if (threadIdx.x == 0) {
+        const unsigned long long first = stamps ? __hip_atomic_load(stamps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : t0;
+        while (__builtin_amdgcn_s_memrealtime() - first < min_ticks) __builtin_amdgcn_s_sleep(32);
+        if (stamps) atomicMax(stamps + 1, __builtin_amdgcn_s_memrealtime());
+    }
+}
+}  // namespace vk
+
+extern "C" int vk_comm_standin(const void* src, void* dst, int64_t bytes, int nwg, int min_usec, uint64_t* stamps, vk_stream_t stream) {
+    if (bytes <= 0 || nwg <= 0) return 0;
+    if ((bytes & 15) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) return vk::set_error("vk_comm_standin: 16-byte granularity");
+    if (nwg > 1024 || min_usec < 0 || min_usec > 100000) return vk::set_error("vk_comm_standin: at most 1024 workgroups, at most 0.1 s");
+    hipLaunchKernelGGL(vk::comm_standin_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, (const vk::u32x4*)src, (vk::u32x4*)dst, (size_t)(bytes / 16),
+                       (unsigned)min_usec * 100u, (unsigned long long*)stamps);
+    return vk::check_launch("vk_comm_standin");
+}
+
+// ---- gate: one wave that holds its stream until another stream's launch has stored the stamp (include/volta_hip.h, vk_gate_wait)
+namespace vk {
+__global__ void gate_wait_kernel(const unsigned long long* flag, const unsigned long long* stamp, unsigned timeout_ticks, int32_t* err) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long want = __hip_atomic_load(stamp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+        __builtin_amdgcn_s_sleep(16);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+            if (err) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+__global__ void bump_u64_kernel(unsigned long long* w) { *w += 1ull; }
+__global__ void store_u64_kernel(unsigned long long* w, unsigned long long v) { __hip_atomic_store(w, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__global__ void gate_value_kernel(const unsigned long long* flag, unsigned long long want, unsigned timeout_ticks, int32_t* err) {
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != want) {
+        __builtin_amdgcn_s_sleep(16);
+        if (__builtin_amdgcn_s_memrealtime() - t0 > timeout_ticks) {
+            if (err) __hip_atomic_store(err, 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+}  // namespace vk
+
+extern "C" int vk_store_u64(uint64_t* word, uint64_t value, vk_stream_t stream) {
+    if (!word) return vk::set_error("vk_store_u64: NULL");
+    hipLaunchKernelGGL(vk::store_u64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)word, (unsigned long long)value);
+    return vk::check_launch("vk_store_u64");
+}
+
+extern "C" int vk_gate_value(const uint64_t* flag, uint64_t want, int timeout_us, int32_t* err, vk_stream_t stream) {
+    if (!flag || timeout_us <= 0 || timeout_us > 10000000) return vk::set_error("vk_gate_value: flag and 0 < timeout_us <= 10000000");
+    hipLaunchKernelGGL(vk::gate_value_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned long long*)flag, (unsigned long long)want,
+                       (unsigned)(timeout_us > 40000000 ? 4000000000u : (unsigned)timeout_us * 100u), err);
+    return vk::check_launch("vk_gate_value");
+}
+
+extern "C" int vk_gate_wait(const uint64_t* flag, const uint64_t* stamp, int timeout_us, int32_t* err, vk_stream_t stream) {
+    if (!flag || !stamp || timeout_us <= 0 || timeout_us > 1000000) return vk::set_error("vk_gate_wait: flag, stamp and 0 < timeout_us <= 1000000");
+    hipLaunchKernelGGL(vk::gate_wait_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (const unsigned long long*)flag, (const unsigned long long*)stamp,
+                       (unsigned)timeout_us * 100u, err);
+    return vk::check_launch("vk_gate_wait");
+}
+
+extern "C" int vk_bump_u64(uint64_t* word, vk_stream_t stream) {
+    if (!word) return vk::set_error("vk_bump_u64: NULL");
+    hipLaunchKernelGGL(vk::bump_u64_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)word);
+    return vk::check_launch("vk_bump_u64");
 }

@@ -247,7 +247,17 @@ class StepEngine:
         self.attn_map_info = []
         self.task_dropout = float(task_dropout)      # BertForVLTasks(dropout_prob=...): nn.Dropout on the fused pooled vector / region states (encoders.py:1118-1122)
         self.fp8 = bool(fp8)
-        self.soft = os.environ.get("VK_SOFT", "1") != "0"        # soft boundaries between dependent GEMMs (0: every launch behind the stream-order barrier)
+        # soft boundaries between dependent GEMMs (VK_GEMM_SOFT_START + row-block counters).  OFF by default: measured neutral in the step
+        # (profiles/r04_experiments.md: on gfx950 a barrier-less dispatch starts on an XCD only when that XCD's workgroups of the launch in
+        # front are done, so there is no tail overlap to win, and the write-through hand-off costs what the shorter boundary saves)
+        self.soft = os.environ.get("VK_SOFT", "0") == "1"
+        self.side_delay_us = int(os.environ.get("VK_SIDE_DELAY_US", "0"))
+        # How a sub-layer's weight-gradient block (side stream) is started: "event" (default) -- the fork event of rounds 1-3; "gate" -- a
+        # one-wave gate at the head of the block that the sub-layer's last dgrad releases as its first workgroup retires, no stream event
+        # (vk_gemm_problem::retire_flag + vk_gate_wait).  Built to take the cross-queue wake-up latency out of the schedule; measured
+        # 0.1-0.2 ms per step slower than the event form and no cure for the slow steps it was built against (those came from a helper
+        # stream on the compute stream's pipe: volta_amd/streams.py, profiles/r04_experiments.md).  Kept as a switch.
+        self.side_gate = os.environ.get("VK_SIDE_START", "event") == "gate"
         dev = arena.device
         self.dev = dev
         H, Hv = cfg.hidden_size, cfg.v_hidden_size
@@ -368,8 +378,10 @@ class StepEngine:
         return cnt.data_ptr() + 4 * cur, cnt.data_ptr()
 
     def soft_error(self):
-        """1 when a guarded tile gave up waiting in some step since the engine was built (host synchronisation: tests and diagnostics)."""
-        return int(self.bufs["soft_cnt"][0].item()) if "soft_cnt" in self.bufs else 0
+        """Non-zero when a guarded tile (1) or a weight-gradient gate (2) gave up waiting in some step since the engine was built (host
+        synchronisation: tests and diagnostics)."""
+        e = int(self.bufs["soft_cnt"][0].item()) if "soft_cnt" in self.bufs else 0
+        return e | (int(self.bufs["gate_err"][0].item()) if "gate_err" in self.bufs else 0)
 
     def _split_launch_done(self, tag):
         self.__dict__.setdefault("_split_cur", {})[tag] = [0, 0]
@@ -1039,7 +1051,7 @@ class StepEngine:
         # dgrad: they need dqkv, not its product, and start beside that GEMM instead of beside the next sub-layer's LayerNorm backward
         self._wgrad(b, ms, shared, [lambda m: (dd[m], ctx[m], self.G(names[m]["o"] + ".weight"), self.G(names[m]["o"] + ".bias"), Hm[m], Ha[m], Hm[m], Ha[m]),
                                     lambda m: (dqkv[m], x_in[m], wqkv(m, "grad"), bqkv(m, "grad"), 3 * Ha[m], Hm[m], 3 * Ha[m], Hm[m])])
-        self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(dqkv[m], wqkv(m, "shadow"), dxn[m], self.st[m].M, Hm[m], 3 * Ha[m], 3 * Ha[m], Hm[m], Hm[m], R=dz[m], ldr=Hm[m]) for m in ms])
+        self.gemm(b, L.NN, L.EPI_ADDR, self.retire_on([self.prob(dqkv[m], wqkv(m, "shadow"), dxn[m], self.st[m].M, Hm[m], 3 * Ha[m], 3 * Ha[m], Hm[m], Hm[m], R=dz[m], ldr=Hm[m]) for m in ms]))
         return b
 
     @staticmethod
@@ -1137,7 +1149,7 @@ class StepEngine:
         # that follows, which it used to keep waiting for CUs (profiles/r03_experiments.md: 17.00 / 16.94 -> 16.52 / 16.54 ms per step).
         self._wgrad(b, ms, shared, [lambda m: (dd[m], h[m], self.G(names[m]["down"] + ".weight"), self.G(names[m]["down"] + ".bias"), Hm[m], Im[m], Hm[m], Im[m]),
                                     lambda m: (du[m], x_in[m], self.G(names[m]["up"] + ".weight"), self.G(names[m]["up"] + ".bias"), Im[m], Hm[m], Im[m], Hm[m])])
-        self.gemm(b, L.NN, L.EPI_ADDR, [self.prob(du[m], self.W(names[m]["up"] + ".weight"), dxn[m], self.st[m].M, Hm[m], Im[m], Im[m], Hm[m], Hm[m], R=dz[m], ldr=Hm[m]) for m in ms])
+        self.gemm(b, L.NN, L.EPI_ADDR, self.retire_on([self.prob(du[m], self.W(names[m]["up"] + ".weight"), dxn[m], self.st[m].M, Hm[m], Im[m], Im[m], Hm[m], Hm[m], R=dz[m], ldr=Hm[m]) for m in ms]))
         return b
 
     def _wgrad(self, b, ms, shared, specs):
@@ -1186,7 +1198,18 @@ class StepEngine:
             reduces.append((gW, slab, stride, len(chunks), Mo * No))
             reduces.append((gB, slab[Mo * No:], stride, len(chunks), Mo))
         assert len(probs) <= 32, "too many wgrad problems in one group"
-        b.append((L.OP_SIDE_BEGIN, 0, 0, 0, None, None, None))
+        gate = self._gate_words() if self.side_gate else None
+        b.append((L.OP_SIDE_BEGIN, 1 if gate is not None else 0, 0, 0, None, None, None))
+        if gate is not None:
+            self._n_gate = getattr(self, "_n_gate", 0) + 1
+            assert self._n_gate < gate.numel()
+            flag = gate.data_ptr() + 8 * self._n_gate
+            b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_GATE, p=(flag, gate.data_ptr(), self.bufs["gate_err"]), n=(1000000,)), None, None))
+            self._gate_flag = (flag, gate.data_ptr())          # the caller hangs it on the dgrad it lists behind this block (retire_on)
+        if self.side_delay_us > 0:
+            # a pure delay (one wave, no LDS) at the head of the block: the dgrad listed behind it on the compute stream has claimed its CUs
+            # before the weight gradients' workgroups arrive, whatever the latency of the cross-queue wake-up (profiles/r04_experiments.md)
+            b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_HOLD, n=(1, self.side_delay_us, 0)), None, None))
         self.gemm(b, L.TN, L.EPI_F32, probs)
         # every slab sum and every deferred LayerNorm dgamma / dbeta reduction of the sub-layer in ONE launch (vk_side_tail)
         jobs = [L.TailJob(_addr(dst), None, _addr(src), None, stride, n, 0, ns, 0, 0) for dst, src, stride, ns, n in reduces]
@@ -1205,6 +1228,27 @@ class StepEngine:
             b.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_SIDE_TAIL, p=(arr,), n=(len(chunk),)), None, None))
         b.append((L.OP_SIDE_END, self.sub_k % 8, 0, 0, None, None, None))
         self._slab_cursor = 0
+
+    def _gate_words(self):
+        """uint64 words of the weight-gradient gates: word 0 = the epoch, bumped by the first launch of every backward pass (the side stream
+        is ordered behind that launch with the one event of the pass); word k = the flag the k-th block's dgrad stores the epoch to."""
+        if "gate_words" not in self.bufs:
+            self.bufs["gate_words"] = torch.zeros(128, dtype=torch.int64, device=self.dev)
+            self.bufs["gate_words"][1:] = -1
+            self.bufs["gate_err"] = torch.zeros(1, dtype=torch.int32, device=self.dev)
+            g = self.bufs["gate_words"]
+            self.bwd_pro.append((L.OP_GENERIC, 0, 0, 0, self.generic(L.FN_BUMP, p=(g,)), None, None))
+            self.bwd_pro.append((L.OP_SIDE_BEGIN, 0, 0, 0, None, None, None))       # an empty block: its fork event orders the side stream behind the bump
+            self.bwd_pro.append((L.OP_SIDE_END, 13, 0, 0, None, None, None))
+        return self.bufs["gate_words"]
+
+    def retire_on(self, probs):
+        """Hang the pending gate flag on a launch's problem 0: its workgroups release the weight-gradient block as they retire."""
+        gf = getattr(self, "_gate_flag", None)
+        if gf is not None:
+            probs[0].retire_flag, probs[0].retire_stamp = gf
+            self._gate_flag = None
+        return probs
 
     def _slab(self, n):
         """fp32 workspace for split-K partials; one arena reused by every sub-layer (launches are stream-ordered)."""

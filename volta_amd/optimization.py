@@ -208,7 +208,11 @@ class AdamW(Optimizer):
         if "stream" not in f:
             n = max(1, min(self._overlap[1], arena.total // 1024))
             nchunks = arena.total // 1024
-            f["stream"] = torch.cuda.Stream(device=arena.device)
+            from .streams import independent_stream, engine_streams
+            ddp = getattr(f["model"], "_ddp", None)
+            comm = getattr(getattr(ddp, "reducer", None), "stream", None)
+            with torch.cuda.device(arena.device):          # clear of the compute, weight-gradient and communication streams' hardware queues
+                f["stream"] = independent_stream(engine_streams(), device=arena.device, soft_avoid=[comm] if comm is not None else [])
             f["bounds"] = [nchunks * (i + 1) // n for i in range(n)]
             f["events"] = [torch.cuda.Event() for _ in range(n)]
         side, bounds, events = f["stream"], f["bounds"], f["events"]

@@ -73,7 +73,13 @@ class BucketReducer:
         self.world = dist.get_world_size(process_group)
         self.rank = dist.get_rank(process_group)
         self.cuda = flat.is_cuda
-        self.stream = torch.cuda.Stream(device=flat.device) if self.cuda else None
+        self.stream = None
+        if self.cuda:
+            # a stream on a hardware queue of its own: one that shares the queue of the compute stream or of the weight-gradient side stream
+            # serialises them behind its waits (volta_amd/streams.py)
+            from .streams import independent_stream
+            with torch.cuda.device(flat.device):
+                self.stream = independent_stream(device=flat.device)
         # apex's scaling (distributed.py:445-454): g *= 1 / predivide, sum over ranks, g *= predivide / world unless gradient_average is off.
         # The default (average, predivide 1) is one AVG collective; anything else sums and scales explicitly.
         self.pre_scale = 1.0 / float(gradient_predivide_factor)
@@ -88,6 +94,13 @@ class BucketReducer:
             raise ValueError("BucketReducer: mode zero1 reduces and gathers in fp32")
         self.bytes_on_wire = 0          # per step, sent by this rank (algorithmic: 2 (w-1)/w x bucket bytes for either mode)
         self._ws = {}
+        # "gate": flags + one-wave gates instead of stream events (vk_store_u64 / vk_gate_value).  Measured equal to the event form once the
+        # communication stream is clear of the compute stream's pipe (profiles/r04_experiments.md); kept as a switch
+        self.gated = os.environ.get("VK_DDP_ORDER", "event") == "gate"
+        self._epoch = 0
+        if self.cuda:
+            self._flags = torch.zeros(2 * 256, dtype=torch.int64, device=flat.device)       # (compute, side) flag per bucket of a pass
+            self._err = torch.zeros(1, dtype=torch.int32, device=flat.device)
         self.begin_step()
 
     def begin_step(self):
@@ -95,6 +108,8 @@ class BucketReducer:
         `replicated` = [(lo, hi)] ranges every rank holds (and steps) in full."""
         self.bytes_on_wire = 0
         self.sharded, self.replicated = [], []
+        self._epoch += 1                # what this pass's flags are set to and its gates wait for
+        self._bucket = 0
 
     def owned(self):
         """Element ranges of the flat arena this rank's optimizer steps under zero1, in arena order."""
@@ -107,10 +122,29 @@ class BucketReducer:
             dist.all_gather_into_tensor(flat[lo:hi], flat[lo + self.rank * s:lo + (self.rank + 1) * s], group=self.pg)
             self.bytes_on_wire += (self.world - 1) * s * flat.element_size()
 
-    def reduce(self, ranges, join=None):
-        """`join`: called with the communication stream current, to make IT (not the compute stream) wait for other
-        producers of the bucket (the executor's weight-gradient side stream)."""
-        if self.cuda:
+    def reduce(self, ranges, join=None, side=None):
+        """Queue the reduction of `ranges` on the communication stream, behind (a) everything enqueued so far on the compute stream and
+        (b) the other producer of the bucket, the executor's weight-gradient side stream.
+        `side`: that stream's raw handle -- the ordering is then made of FLAGS and GATES (vk_store_u64 on the compute and the side stream,
+        vk_gate_value on the communication stream), not of stream events: an unsatisfied `wait_event` enqueued a step ahead sits at the
+        head of the communication queue for milliseconds and stalls the queues that share its command-processor pipe (measured: 19-25 ms
+        per step instead of 16.9, by which pool stream the reducer happened to get; profiles/r04_experiments.md).
+        `join` (without `side`): the event form -- called with the communication stream current, to make it wait for the side stream."""
+        if self.cuda and side is not None and self.gated:
+            import ctypes as C
+            from . import _lib as L
+            k = self._bucket
+            self._bucket += 1
+            if k >= self._flags.numel() // 2:
+                raise RuntimeError("BucketReducer: more than %d buckets in one backward pass" % (self._flags.numel() // 2))
+            f_main, f_side = self._flags.data_ptr() + 16 * k, self._flags.data_ptr() + 16 * k + 8
+            L.check(L.lib.vk_store_u64(C.c_void_p(f_main), self._epoch, L.stream_ptr()))
+            L.check(L.lib.vk_store_u64(C.c_void_p(f_side), self._epoch, C.c_void_p(side)))
+            with torch.cuda.stream(self.stream):
+                L.check(L.lib.vk_gate_value(C.c_void_p(f_main), self._epoch, 10000000, L.ptr(self._err), L.stream_ptr()))
+                L.check(L.lib.vk_gate_value(C.c_void_p(f_side), self._epoch, 10000000, L.ptr(self._err), L.stream_ptr()))
+                self._reduce(ranges)
+        elif self.cuda:
             ev = torch.cuda.Event()
             ev.record()
             with torch.cuda.stream(self.stream):
@@ -259,9 +293,22 @@ class DistributedDataParallel(nn.Module):
     def forward(self, *args, **kwargs):
         return self.module(*args, **kwargs)
 
+    @staticmethod
+    def _side_handle(owner):
+        """Raw handle of the executor's weight-gradient side stream of compute stream `owner` (None on CPU)."""
+        if owner is None:
+            return None
+        import ctypes as C
+        from . import _lib as L
+        h = L.lib.vk_side_stream(C.c_void_p(owner))
+        if not h:
+            raise RuntimeError(L.lib.vk_last_error().decode())
+        return int(h)
+
     def _plan(self, eng):
         plan = getattr(eng, "_ddp_plan", None)      # lives and dies with the engine it describes
-        if plan is None or plan[0] != self.message_size:
+        key = (self.message_size, self.delay_allreduce)
+        if plan is None or plan[0] != key:
             arena = eng.arena
             spans = {}
             for n in arena.params:
@@ -272,7 +319,7 @@ class DistributedDataParallel(nn.Module):
             n_stages = len(eng.bwd_marks)
             cap = (1 << 62) if self.delay_allreduce else self.message_size * 4      # delay_allreduce: one bucket, cut after the last stage
             buckets = plan_buckets(spans, eng.param_ready_stage, n_stages, cap, pad_to=SLOT, total=arena.total)
-            plan = (self.message_size, [(eng.bwd_marks[s], ranges) for s, ranges in buckets])
+            plan = (key, [(eng.bwd_marks[s], ranges) for s, ranges in buckets])
             eng._ddp_plan = plan
         return plan[1]
 
@@ -301,7 +348,7 @@ class DistributedDataParallel(nn.Module):
             eng.bwd.run(start, end)
             # the bucket's weight gradients were computed on the executor's side stream: the communication stream waits
             # for them, the compute stream carries on with the backward
-            self.reducer.reduce(ranges, join=lambda: eng.bwd.join_side(owner))
+            self.reducer.reduce(ranges, join=lambda: eng.bwd.join_side(owner), side=self._side_handle(owner))
             start = end
         eng.bwd.run(start, len(eng.bwd.ops))
         self.reducer.finish()
