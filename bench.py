@@ -52,12 +52,15 @@ def gemm_flops(eng, plan):
     from volta_amd import _lib as L
     out, bytes_out = {}, {}
     for i, (kind, layout, epi, nprob, arr, _, _) in enumerate(plan.ops):
-        if kind not in (L.OP_GEMM, L.OP_GEMM_FP8):
+        if kind not in (L.OP_GEMM, L.OP_GEMM_FP8, L.OP_GEMM_CHAIN):
             continue
         layout &= 0xFF                     # the op carries a tile geometry above the layout
         fl, by = 0.0, 0.0
-        for j in range(nprob):
-            q = arr[j].p if kind == L.OP_GEMM_FP8 else arr[j]
+        if kind == L.OP_GEMM_CHAIN:        # producers (a) then consumers (b) of one persistent launch; epilogues packed in `epi`
+            probs = [(arr[j], epi & 0xFF) for j in range(nprob & 0xFF)] + [(plan.ops[i][5][j], epi >> 8) for j in range(nprob >> 8)]
+        else:
+            probs = [((arr[j].p if kind == L.OP_GEMM_FP8 else arr[j]), epi) for j in range(nprob)]
+        for q, epi in probs:
             M, K = q.M, q.K
             if q.dyn:
                 n = int(_dev_int(q.dyn, eng).item())
@@ -361,14 +364,18 @@ def main():
             kinds = {}
             for plan, tag in ((eng.fwd, "f"), (eng.bwd, "b")):
                 for i, op in enumerate(plan.ops):
-                    name = {L.OP_GEMM: "gemm", L.OP_GEMM_FP8: "gemm_fp8", L.OP_LN_FWD: "ln_fwd", L.OP_LN_BWD: "ln_bwd", L.OP_ATTN_FWD: "attn_fwd", L.OP_ATTN_BWD: "attn_bwd"}.get(op[0], "other")
+                    name = {L.OP_GEMM: "gemm", L.OP_GEMM_CHAIN: "gemm", L.OP_GEMM_FP8: "gemm_fp8", L.OP_LN_FWD: "ln_fwd", L.OP_LN_BWD: "ln_bwd", L.OP_ATTN_FWD: "attn_fwd", L.OP_ATTN_BWD: "attn_bwd"}.get(op[0], "other")
                     kinds[name] = kinds.get(name, 0.0) + tms["%s%d" % (tag, i)]
             if a.dump_ops:
                 with open(a.dump_ops, "w") as fh:
                     for plan, tag in ((eng.fwd, "f"), (eng.bwd, "b")):
                         for i, op in enumerate(plan.ops):
                             key = "%s%d" % (tag, i)
-                            if op[0] in (L.OP_GEMM, L.OP_GEMM_FP8):
+                            if op[0] == L.OP_GEMM_CHAIN:
+                                pr = [op[4][j] for j in range(op[3] & 0xFF)] + [op[5][j] for j in range(op[3] >> 8)]
+                                fh.write("%s gemm chain layout=%d epi=%d->%d [%s] %.1f us %.0f TF/s\n" % (key, op[1], op[2] & 0xFF, op[2] >> 8, ";".join("%dx%dx%d" % (q.M, q.N, q.K) for q in pr),
+                                                                                                       tms[key] * 1e3, fl[key] / (tms[key] * 1e-3) / 1e12))
+                            elif op[0] in (L.OP_GEMM, L.OP_GEMM_FP8):
                                 arr, nprob = op[4], op[3]
                                 pr = [(arr[j].p if op[0] == L.OP_GEMM_FP8 else arr[j]) for j in range(min(nprob, 4))]
                                 shapes = ("fp8 " if op[0] == L.OP_GEMM_FP8 else "") + ";".join("%dx%dx%d" % (q.M, q.N, q.K) for q in pr)

@@ -122,6 +122,14 @@ int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* probs, int 
  * dispatched in enqueue order -- tools/micro/dispatch_order.hip -- so a polling workgroup never holds a CU that a producer still needs.) */
 #define VK_GEMM_SOFT_START 0x4000
 int vk_gemm_grouped_ex(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, int geometry, vk_stream_t s);
+/* Chain: a producer group and the consumer group that reads its outputs in ONE persistent launch (the reference's BertGatedIntermediate ->
+ * BertGatedOutput pair, volta/encoders.py:486-501 -> 541-566, and its backward: FFN-down dgrad x gelu' -> FFN-up dgrad).  Producers run on
+ * 256 x 256 tiles with epilogue `epi_p` and signal row blocks (`sig`); consumers run on 256 x 192 tiles with epilogue `epi_c`, each reads
+ * ONE producer's C as its A operand (A = that C, M, K = its N, lda = its ldc) and names that producer's counters in `dep`, dep_need = N / 256.
+ * One workgroup per CU walks its producer tiles, then its consumer tiles behind the row-block polls: no launch boundary between the two
+ * products, early finishers start on consumer tiles while the others finish.  Whole tiles only; counters zero before the launch; err as
+ * for the hand-off.  Built pairs: NT with GELU -> BF16, NN with MULR -> ADDR. */
+int vk_gemm_chain(int layout, int epi_p, const vk_gemm_problem* producers, int np, int epi_c, const vk_gemm_problem* consumers, int nc, vk_stream_t s);
 /* Workspace of a split accumulation (see vk_gemm_problem::ws): bytes of `ws` for one product [M, N] cut into `nparts` parts under tile
  * geometry 258 / 259; *tiles receives the number of int32 counters `cnt` needs.  Host-side arithmetic, no device work. */
 size_t vk_gemm_split_workspace_bytes(int layout, int M, int N, int nparts, int geometry, int* tiles);
@@ -525,7 +533,8 @@ enum {
        if never recorded), JOIN makes it wait for everything issued on the side stream. */
     VK_OP_SIDE_BEGIN, VK_OP_SIDE_END, VK_OP_WAIT_SIDE, VK_OP_JOIN,
     VK_OP_LN_FINALIZE,   /* a = vk_ln_bwd_args of the deferred vk_ln_bwd */
-    VK_OP_GEMM_FP8       /* a = vk_gemm_fp8_problem[i2], i1 = epilogue, i0 = geometry */
+    VK_OP_GEMM_FP8,      /* a = vk_gemm_fp8_problem[i2], i1 = epilogue, i0 = geometry */
+    VK_OP_GEMM_CHAIN     /* vk_gemm_chain: a = producers[i2 & 0xFF], b = consumers[i2 >> 8], i0 = layout, i1 = epi_p | epi_c << 8 */
 };
 enum {
     VK_FN_CAST = 1, VK_FN_MEMSET, VK_FN_LOC_FWD, VK_FN_LOC_BWD, VK_FN_ADD_DROPOUT, VK_FN_COLSUM, VK_FN_SELECT,

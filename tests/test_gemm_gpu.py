@@ -357,3 +357,123 @@ def test_soft_boundary_rejects_what_it_cannot_guard():
     upr, downr, cntr, _, _, keepr = _ffn_pair(L, ops, (300,), 512, 768, seed=1, soft=True)      # ragged rows
     with pytest.raises(RuntimeError):
         ops.gemm_grouped(L.NT, L.EPI_GELU, upr, geometry=258)
+
+
+# ---- vk_gemm_chain: producer group + consumer group in ONE persistent launch
+def _chain_pair(L, ops, rows, I, H, seed, which):
+    """which = "fwd": FFN-up + GELU -> FFN-down (NT); "bwd": FFN-down dgrad x gelu' -> FFN-up dgrad + residual gradient (NN)."""
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    cnt = torch.zeros(32 + 64 * len(rows) + sum(M // 256 for M in rows), device="cuda", dtype=torch.int32)
+    P, Cn, outs, keep, sigs = [], [], [], [], []
+    cur = 32
+    for M in rows:
+        if which == "fwd":
+            x, W1, W2 = rnd((M, H), g, 0.5), rnd((I, H), g, 0.05), rnd((H, I), g, 0.05)
+            b1, b2 = torch.randn(I, generator=g, device="cuda") * 0.1, torch.randn(H, generator=g, device="cuda") * 0.1
+            mid, mid2 = (torch.full((M, I), float("nan"), device="cuda", dtype=torch.bfloat16) for _ in range(2))
+            out = torch.full((M, H), float("nan"), device="cuda", dtype=torch.bfloat16)
+            pp = ops.gemm_problem(x, W1, mid, L.NT, M, I, H, bias=b1, C2=mid2)
+            pc = ops.gemm_problem(mid, W2, out, L.NT, M, H, I, bias=b2)
+            keep += [x, W1, W2, b1, b2]
+        else:
+            dd, Wd, Wu = rnd((M, H), g, 0.5), rnd((H, I), g, 0.05), rnd((I, H), g, 0.05)
+            gp, dz = rnd((M, I), g, 0.5), rnd((M, H), g, 0.5)
+            mid = torch.full((M, I), float("nan"), device="cuda", dtype=torch.bfloat16)
+            mid2 = None
+            out = torch.full((M, H), float("nan"), device="cuda", dtype=torch.bfloat16)
+            pp = ops.gemm_problem(dd, Wd, mid, L.NN, M, I, H, R=gp)
+            pc = ops.gemm_problem(mid, Wu, out, L.NN, M, H, I, R=dz)
+            keep += [dd, Wd, Wu, gp, dz]
+        sig = cnt.data_ptr() + 4 * cur
+        pp.sig, pp.err = sig, cnt.data_ptr()
+        pc.dep, pc.err, pc.dep_need = sig, cnt.data_ptr(), I // 256
+        sigs.append(cnt[cur:cur + M // 256])
+        cur += (M // 256 + 31) // 32 * 32
+        P.append(pp); Cn.append(pc); outs.append((mid, mid2, out))
+    return P, Cn, cnt, sigs, outs, keep
+
+
+def _plain(p):
+    """The same problem without the hand-off fields: for the two-launch reference."""
+    import ctypes
+    q = type(p)()
+    ctypes.memmove(ctypes.byref(q), ctypes.byref(p), ctypes.sizeof(p))
+    q.sig = q.dep = q.err = None
+    q.dep_need = 0
+    return q
+
+
+@pytest.mark.parametrize("which", ["fwd", "bwd"])
+@pytest.mark.parametrize("rows", [(5120, 9472), (5120,), (256,), (1024, 256)])
+def test_gemm_chain_equals_the_two_launches(which, rows, tile_edge):
+    """Producers and consumers in one persistent launch, consumers behind row-block polls: the two launches' bits, on every one of 20
+    back-to-back runs, counters at their column-tile count, error word clear."""
+    if tile_edge != 0:
+        pytest.skip("the chain names its own geometries")
+    L, ops = _mods()
+    I, H = 3072, 768
+    layout, ep, ec = (L.NT, L.EPI_GELU, L.EPI_BF16) if which == "fwd" else (L.NN, L.EPI_MULR, L.EPI_ADDR)
+    P, Cn, cnt, sigs, outs, keep = _chain_pair(L, ops, rows, I, H, 21, which)
+    ops.gemm_grouped(layout, ep, [_plain(p) for p in P], geometry=258)
+    ops.gemm_grouped(layout, ec, [_plain(p) for p in Cn], geometry=259)
+    torch.cuda.synchronize()
+    want = [(m.clone(), m2.clone() if m2 is not None else None, o.clone()) for m, m2, o in outs]
+    assert all(torch.isfinite(o.float()).all() for _, _, o in want)
+    for rep in range(20):
+        for m, m2, o in outs:
+            m.fill_(float("nan")); o.fill_(float("nan"))
+        cnt[1:].zero_()
+        ops.gemm_chain(layout, ep, P, ec, Cn)
+        torch.cuda.synchronize()
+        assert int(cnt[0]) == 0, "a guarded tile gave up waiting"
+        assert all(bool((s == I // 256).all()) for s in sigs)
+        for (m, m2, o), (wm, wm2, wo) in zip(outs, want):
+            assert torch.equal(m, wm) and (m2 is None or torch.equal(m2, wm2)), "producer output differs (rep %d)" % rep
+            assert torch.equal(o, wo), "a consumer tile read a row block before it was complete (rep %d): %d elements differ" % (rep, int((o != wo).sum()))
+
+
+def test_gemm_chain_under_uneven_load_and_with_reserved_cus():
+    """A second stream holds CUs while the chain runs (workgroups that start late, consumers that wait long), and the chain on a grid
+    that leaves CUs unclaimed (vk_gemm_reserve_cus): the same bits, nobody hangs."""
+    L, ops = _mods()
+    rows, I, H = (5120, 9472), 3072, 768
+    P, Cn, cnt, sigs, outs, keep = _chain_pair(L, ops, rows, I, H, 8, "fwd")
+    ops.gemm_grouped(L.NT, L.EPI_GELU, [_plain(p) for p in P], geometry=258)
+    ops.gemm_grouped(L.NT, L.EPI_BF16, [_plain(p) for p in Cn], geometry=259)
+    torch.cuda.synchronize()
+    want = [o.clone() for _, _, o in outs]
+    side = torch.cuda.Stream()
+    try:
+        for rep, (nwg, usec, reserve) in enumerate([(64, 150, 0), (128, 60, 0), (200, 100, 0), (255, 30, 0), (0, 0, 32), (64, 200, 64)]):
+            L.lib.vk_gemm_reserve_cus(reserve)
+            for m, m2, o in outs:
+                m.fill_(float("nan")); o.fill_(float("nan"))
+            cnt[1:].zero_()
+            torch.cuda.synchronize()
+            if nwg:
+                L.check(L.lib.vk_hold_cus(nwg, usec, 1, ctypes_ptr(side)))
+            ops.gemm_chain(L.NT, L.EPI_GELU, P, L.EPI_BF16, Cn)
+            if nwg:
+                L.check(L.lib.vk_hold_cus(nwg, usec // 2, 1, ctypes_ptr(side)))
+            torch.cuda.synchronize()
+            assert int(cnt[0]) == 0, "a guarded tile gave up waiting"
+            for (m, m2, o), wo in zip(outs, want):
+                assert torch.equal(o, wo), "rep %d (%d CUs held for %d us, %d reserved)" % (rep, nwg, usec, reserve)
+    finally:
+        L.lib.vk_gemm_reserve_cus(0)
+
+
+def test_gemm_chain_rejects_what_it_cannot_run():
+    L, ops = _mods()
+    P, Cn, cnt, sigs, outs, keep = _chain_pair(L, ops, (512,), 512, 768, 1, "fwd")
+    with pytest.raises(RuntimeError):
+        ops.gemm_chain(L.NT, L.EPI_BF16, P, L.EPI_BF16, Cn)            # not a built epilogue pair
+    bad = _plain(Cn[0])
+    with pytest.raises(RuntimeError):
+        ops.gemm_chain(L.NT, L.EPI_GELU, P, L.EPI_BF16, [bad])         # a consumer without dep
+    Cn[0].dep_need = 1
+    with pytest.raises(RuntimeError):
+        ops.gemm_chain(L.NT, L.EPI_GELU, P, L.EPI_BF16, Cn)            # does not wait for every column tile
+    P2, Cn2, *_ = _chain_pair(L, ops, (300,), 512, 768, 1, "fwd")
+    with pytest.raises(RuntimeError):
+        ops.gemm_chain(L.NT, L.EPI_GELU, P2, L.EPI_BF16, Cn2)          # ragged rows

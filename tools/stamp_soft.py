@@ -46,4 +46,35 @@ def main():
                       q(kk[:, 0], 0), q(kk[:, 0], .5), q(kk[:, 0], 1), q(kk[:, 1], 0), q(kk[:, 1], .5), q(kk[:, 1], 1), q(kk[:, 2], 0), q(kk[:, 2], .5), q(kk[:, 2], 1)), flush=True)
 
 
-main()
+def chain():
+    """The same pair as ONE persistent launch (vk_gemm_chain): producer rounds in stamp slots 0-3, consumer rounds in slots 4-7."""
+    L.lib.vk_gemm_set_stamp_buffer.argtypes = [ctypes.c_void_p]
+    pst = torch.zeros(256 * 8 * 4, dtype=torch.int64, device="cuda")
+    P, Cn, cnt, sigs, outs, keep = T._chain_pair(L, ops, (5120, 9472), 3072, 768, 3, "fwd")
+    flush = torch.empty(300 * 1024 * 1024, dtype=torch.bfloat16, device="cuda")
+    for it in range(6):
+        pst.zero_(); cnt[1:].zero_()
+        if it >= 3:
+            flush.fill_(1.0)
+        torch.cuda.synchronize()
+        L.lib.vk_gemm_set_stamp_buffer(pst.data_ptr())
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ops.gemm_chain(L.NT, L.EPI_GELU, P, L.EPI_BF16, Cn)
+        e1.record()
+        torch.cuda.synchronize()
+        L.lib.vk_gemm_set_stamp_buffer(None)
+        p = pst.view(256, 8, 4).cpu().double() / 100.0
+        t0 = p[:, 0, 0][p[:, 0, 0] > 0].min()
+        pend = p[:, :4, 3].max(dim=1).values - t0
+        has_c = p[:, 4, 0] > 0
+        cs, cw, ce = p[has_c, 4, 0] - t0, p[has_c, 4, 1] - t0, p[has_c, 4, 3] - t0
+        q = lambda x, f: float(x.sort().values[int(f * (len(x) - 1))])
+        print("chain %s it %d: launch %.1f us (events) | producer tiles end %.1f / %.1f / %.1f (min / median / max) | %d consumer tiles: K loop starts %.1f / %.1f / %.1f, ends %.1f / %.1f / %.1f, tile ends %.1f / %.1f / %.1f" % (
+            "cold" if it >= 3 else "hot ", it, e0.elapsed_time(e1) * 1e3, q(pend, 0), q(pend, .5), q(pend, 1), int(has_c.sum()), q(cs, 0), q(cs, .5), q(cs, 1), q(cw, 0), q(cw, .5), q(cw, 1), q(ce, 0), q(ce, .5), q(ce, 1)), flush=True)
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "chain":
+    chain()
+else:
+    main()

@@ -143,7 +143,7 @@ class Op(C.Structure):
 
 
 (OP_GEMM, OP_LN_FWD, OP_LN_BWD, OP_ATTN_FWD, OP_ATTN_BWD, OP_EMBED_FWD, OP_EMBED_BWD, OP_XENT_FWD, OP_XENT_BWD,
- OP_KL_FWD, OP_KL_BWD, OP_GENERIC, OP_SIDE_BEGIN, OP_SIDE_END, OP_WAIT_SIDE, OP_JOIN, OP_LN_FINALIZE, OP_GEMM_FP8) = range(1, 19)
+ OP_KL_FWD, OP_KL_BWD, OP_GENERIC, OP_SIDE_BEGIN, OP_SIDE_END, OP_WAIT_SIDE, OP_JOIN, OP_LN_FINALIZE, OP_GEMM_FP8, OP_GEMM_CHAIN) = range(1, 20)
 (FN_CAST, FN_MEMSET, FN_LOC_FWD, FN_LOC_BWD, FN_ADD_DROPOUT, FN_COLSUM, FN_SELECT, FN_GATHER, FN_SCATTER_ADD,
  FN_LOSS_FINAL, FN_POOL_FWD, FN_POOL_BWD, FN_MASK_PREP, FN_MUL, FN_VLBERT_PREP, FN_VLBERT_MASKGRAD, FN_ROWGROUP_SUM,
  FN_RELU_BWD, FN_COPY, FN_SUM_SLABS, FN_SUM_SLABS_BF16, FN_SIDE_TAIL, FN_QUANT_ROWS, FN_CAST_FP8, FN_VIS_LOSS_FWD, FN_VIS_LOSS_BWD,
@@ -181,6 +181,7 @@ _sig("vk_gemm_fp8_grouped", C.c_int, C.c_int, C.POINTER(GemmFp8Problem), C.c_int
 _sig("vk_quant_rows_fp8", C.c_int, c_p, C.c_int, C.c_int64, c_p, C.c_int64, c_p, C.c_int, C.c_int, c_p, c_p)
 _sig("vk_cast_bf16_fp8", C.c_int, c_p, c_p, C.c_int64, C.c_float, c_p)
 _sig("vk_gemm_grouped_ex", C.c_int, C.c_int, C.c_int, C.POINTER(GemmProblem), C.c_int, C.c_int, c_p)
+_sig("vk_gemm_chain", C.c_int, C.c_int, C.c_int, C.POINTER(GemmProblem), C.c_int, C.c_int, C.POINTER(GemmProblem), C.c_int, c_p)
 _sig("vk_gemm_split_workspace_bytes", C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int))
 _sig("vk_gated_attn_fwd", C.c_int, C.POINTER(AttnArgs), c_p)
 _sig("vk_gated_attn_bwd", C.c_int, C.POINTER(AttnArgs), C.POINTER(AttnBwdArgs), c_p)
@@ -263,7 +264,7 @@ _sig("vk_side_join_from", C.c_int, c_p, c_p)
 _sig("vk_side_enable", None, C.c_int)
 _sig("vk_side_stream", c_p, c_p)
 
-EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_cast_f32_bf16", "vk_gemm_grouped", "vk_gemm_grouped_ex", "vk_gemm_split_workspace_bytes", "vk_gemm_fp8_grouped", "vk_quant_rows_fp8", "vk_cast_bf16_fp8",
+EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_cast_f32_bf16", "vk_gemm_grouped", "vk_gemm_grouped_ex", "vk_gemm_chain", "vk_gemm_split_workspace_bytes", "vk_gemm_fp8_grouped", "vk_quant_rows_fp8", "vk_cast_bf16_fp8",
            "vk_ln_fwd", "vk_ln_fwd_pair", "vk_ln_bwd_partial_rows", "vk_ln_bwd", "vk_ln_bwd_pair", "vk_ln_bwd_finalize", "vk_gated_attn_fwd", "vk_gated_attn_bwd",
            "vk_embed_sum_fwd", "vk_embed_sum_bwd", "vk_rows32", "vk_loc_linear_fwd", "vk_loc_linear_bwd",
            "vk_add_dropout", "vk_colsum_bf16", "vk_vlbert_prep_fwd", "vk_vlbert_maskgrad", "vk_rowgroup_sum_bf16",

@@ -155,6 +155,7 @@ static int run_one(const vk_op& o, int i, vk_stream_t s) {
         switch (o.kind) {
             case VK_OP_GEMM: rc = vk_gemm_grouped_ex(o.i0 & 0xFF, o.i1, (const vk_gemm_problem*)o.a, o.i2, o.i0 >> 8, s); break;      /* i0: layout | tile geometry << 8 (0 = heuristic) */
             case VK_OP_GEMM_FP8: rc = vk_gemm_fp8_grouped(o.i1, (const vk_gemm_fp8_problem*)o.a, o.i2, o.i0, s); break;
+            case VK_OP_GEMM_CHAIN: rc = vk_gemm_chain(o.i0, o.i1 & 0xFF, (const vk_gemm_problem*)o.a, o.i2 & 0xFF, o.i1 >> 8, (const vk_gemm_problem*)o.b, o.i2 >> 8, s); break;
             case VK_OP_LN_FWD: rc = vk_ln_fwd_pair((const vk_ln_args*)o.a, (const vk_ln_args*)o.b, s); break;
             case VK_OP_LN_BWD: rc = vk_ln_bwd_pair((const vk_ln_bwd_args*)o.a, (const vk_ln_bwd_args*)o.b, s); break;
             case VK_OP_LN_FINALIZE: rc = vk_ln_bwd_finalize((const vk_ln_bwd_args*)o.a, s); break;

@@ -400,6 +400,54 @@ extern "C" size_t vk_gemm_split_workspace_bytes(int layout, int M, int N, int np
     return (size_t)nt * (size_t)nparts * per;
 }
 
+extern "C" int vk_gemm_chain(int layout, int epi_p, const vk_gemm_problem* prod, int np, int epi_c, const vk_gemm_problem* cons, int nc, vk_stream_t stream) {
+    using namespace vk;
+    if (np < 1 || nc < 1 || np + nc > VK_GEMM_MAX_GROUP) return set_error("vk_gemm_chain: %d + %d problems (1 .. %d in all)", np, nc, VK_GEMM_MAX_GROUP);
+    if (layout != VK_NT && layout != VK_NN) return set_error("vk_gemm_chain: layout %d (NT / NN)", layout);
+    KGroup g{};
+    g.nprob = np + nc;
+    g.stagger = 0;
+    int total = 0, nprod = 0;
+    for (int i = 0; i < np + nc; ++i) {
+        const bool is_p = i < np;
+        const vk_gemm_problem& q = is_p ? prod[i] : cons[i - np];
+        const int bn = is_p ? 256 : 192;
+        if (q.M <= 0 || q.N <= 0 || q.K <= 0 || (q.M & 255) || (q.N % bn) || (q.K & 63)) return set_error("vk_gemm_chain: problem %d: whole tiles only (M %% 256, N %% %d, K %% 64; got %d %d %d)", i, bn, q.M, q.N, q.K);
+        if ((q.lda & 7) || (q.ldb & 7) || (q.ldc & 3) || ((uintptr_t)q.A & 15) || ((uintptr_t)q.B & 15) || ((uintptr_t)q.C & 15)) return set_error("vk_gemm_chain: operand alignment (problem %d)", i);
+        if (q.dyn || q.nparts > 1 || q.bias_grad) return set_error("vk_gemm_chain: no dyn / split accumulation / bias gradient (problem %d)", i);
+        const uint64_t ea = (uint64_t)q.M * q.lda * 2, eb = (uint64_t)(layout == VK_NT ? q.N : q.K) * q.ldb * 2;
+        if (ea >= 0x7FFFFFF0ull || eb >= 0x7FFFFFF0ull) return set_error("vk_gemm_chain: operands must stay below 2 GiB");
+        if (is_p) {
+            if (!q.sig || q.dep || ((q.ldc * 2) & 127) || ((uintptr_t)q.C & 127)) return set_error("vk_gemm_chain: producer %d needs sig, no dep, and C rows 128-byte aligned", i);
+            if (epi_p == VK_EPI_GELU && !q.C2) return set_error("vk_gemm_chain: C2 missing");
+            if (epi_p == VK_EPI_MULR && !q.R) return set_error("vk_gemm_chain: R missing");
+        } else {
+            // a consumer reads the C of ONE producer through its A operand and waits for that producer's counters: every column tile of the row block
+            int src = -1;
+            for (int j = 0; j < np; ++j)
+                if (prod[j].sig == q.dep) src = j;
+            if (src < 0 || q.sig) return set_error("vk_gemm_chain: consumer %d: dep must be a producer's sig (and no sig of its own)", i - np);
+            const vk_gemm_problem& pr = prod[src];
+            if (q.A != pr.C || q.M != pr.M || q.K != pr.N || q.lda != pr.ldc || q.dep_need != pr.N / 256)
+                return set_error("vk_gemm_chain: consumer %d does not read producer %d's C as its A operand (A, M, K, lda, dep_need = N / 256)", i - np, src);
+            if (epi_c == VK_EPI_ADDR && !q.R) return set_error("vk_gemm_chain: R missing");
+        }
+        KProb& k = g.p[i];
+        k.A = (const char*)q.A; k.B = (const char*)q.B; k.C = (char*)q.C; k.C2 = (char*)q.C2; k.bias = q.bias;
+        k.R = (const char*)q.R; k.bias_grad = nullptr; k.dyn = nullptr; k.C8 = nullptr; k.c8_mul = 0.f; k.ldc8 = 0;
+        k.M = q.M; k.N = q.N; k.K = q.K; k.lda = q.lda; k.ldb = q.ldb; k.ldc = q.ldc; k.ldr = q.ldr; k.n_store = 0;
+        k.ws = nullptr; k.cnt = nullptr; k.part = 0; k.nparts = 0;
+        k.sig = q.sig; k.dep = q.dep; k.err = q.err; k.dep_need = q.dep_need;
+        k.tiles_n = q.N / bn;
+        k.tile_start = total;
+        total += (q.M / 256) * k.tiles_n;
+        if (is_p) nprod = total;
+    }
+    g.retire_flag = (unsigned long long*)prod[0].retire_flag; g.retire_stamp = (const unsigned long long*)prod[0].retire_stamp;
+    if (g.retire_flag && (!g.retire_stamp || ((uintptr_t)g.retire_flag & 7) || ((uintptr_t)g.retire_stamp & 7))) return set_error("vk_gemm_chain: retire_flag needs retire_stamp, both 8-byte aligned");
+    return launch_gemm256_chain(layout, epi_p, epi_c, g, nprod, total - nprod, (hipStream_t)stream);
+}
+
 extern "C" int vk_gemm_grouped(int layout, int epilogue, const vk_gemm_problem* probs, int nprob, vk_stream_t stream) {
     return gemm_dispatch(layout, epilogue, probs, nprob, 0, stream);
 }

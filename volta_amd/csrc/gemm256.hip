@@ -396,8 +396,31 @@ __global__ __launch_bounds__(512) void gemm256k_kernel(const KGroup g) {
 // retires, and launch ramp + end-of-kernel write-back are paid once per launch instead of once per round.
 // vmcnt counts loads and stores together in issue order: the next tile's prologue loads are OLDER than the epilogue's stores, so the
 // loop's first `vmcnt(8)` (all but the 8 youngest operations done) covers them -- conservatively, it also waits for most stores.
-template <bool AT, bool BT, int EPI, int TJ>
-__global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int total, unsigned long long* const stamps) {
+// Tile iterators of the persistent walk: next() yields the next tile index of THIS workgroup (already in XCD-chunked order) or -1.
+struct StrideTiles {            // v = blockIdx.x, + gridDim.x, ...: the whole tile list of a launch
+    int v, total;
+    __device__ __forceinline__ int next() { const int t = v < total ? xcd_remap(v, total) : -1; v += (int)gridDim.x; return t; }
+};
+// A chain launch (vk_gemm_chain): tiles [0, nprod) are the producers' (walked first, by every workgroup), [nprod, nprod + ncons) the
+// consumers'.  Consumer tiles are dealt in REVERSE inside an XCD's chunk: the workgroups with one producer tile fewer (the high
+// blockIdx.x) finish first and take the chunk's first row blocks, which the XCD completes first.
+struct ProducerTiles {
+    int v, nprod;
+    __device__ __forceinline__ int next() { const int t = v < nprod ? xcd_remap(v, nprod) : -1; v += (int)gridDim.x; return t; }
+};
+struct ConsumerTiles {
+    int k, nprod, ncons;        // k: this workgroup's rank inside its XCD, + workgroups per XCD per round
+    __device__ __forceinline__ int next() {
+        const int x = blockIdx.x & 7, q = ncons >> 3, r = ncons & 7;
+        const int len = q + (x < r ? 1 : 0), start = x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+        const int local = len - 1 - k;
+        k += (int)(gridDim.x >> 3);
+        return local >= 0 ? nprod + start + local : -1;
+    }
+};
+
+template <bool AT, bool BT, int EPI, int TJ, typename Tiles>
+__device__ __forceinline__ void persistent_walk(const KGroup& g, Tiles tiles, unsigned long long* const stamps) {
     // `stamps` (study builds; NULL in the shipped library's launches): per workgroup and tile four s_memrealtime readings (100 MHz) --
     // loop top, K loop done, ring drained + next prologue issued, epilogue done -- into a buffer no other code reads.
     static_assert(!(AT && BT), "the persistent kernel serves the NT / NN layouts (no bias-gradient accumulators)");
@@ -414,8 +437,7 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int
     bool guarded;
     __amdgpu_buffer_rsrc_t rsA, rsB;
     uint32_t offA[2], offB[2], kA, kB;
-    auto setup = [&](int v) {
-        const int bid = xcd_remap(v, total);
+    auto setup = [&](int bid) {
         pi = 0;
 #pragma nounroll
         for (int i = 1; i < g.nprob; ++i)              // scalar loop: an unrolled search keeps 32 tile_start words live across the tile loop
@@ -443,18 +465,19 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int
         stage_half(rsB, sa + HT, offB, live ? (uint32_t)p * kB : OOB, wave);
     };
 
-    int v = blockIdx.x;
-    setup(v);
+    int tile = tiles.next();
+    if (tile < 0) return;
+    setup(tile);
     if (guarded) soft_wait(g.p[pi].dep, m0 >> 8, g.p[pi].dep_need, g.p[pi].err);
     stage(0, 0); stage(1, 1); stage(2, 2);
-    for (;;) {
+    for (int round = 0;; ++round) {
         f32x4 acc[8][TJ];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
 #pragma unroll
             for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        unsigned long long* const st = stamps ? stamps + ((size_t)blockIdx.x * 8 + (size_t)((v - (int)blockIdx.x) / (int)gridDim.x)) * 4 : nullptr;
-        const bool stamping = st != nullptr && tid == 0 && (v - (int)blockIdx.x) / (int)gridDim.x < 8;
+        unsigned long long* const st = stamps ? stamps + ((size_t)blockIdx.x * 8 + (size_t)round) * 4 : nullptr;
+        const bool stamping = st != nullptr && tid == 0 && round < 8;
         if (stamping) st[0] = __builtin_amdgcn_s_memrealtime();
         VK_WAIT_DMA();
         VK_SYNC();
@@ -489,11 +512,11 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int
         VK_SYNC();                                            // ... of every wave: the whole ring is free
 
         const int cpi = pi, cm0 = m0, cn0 = n0;
-        const int nv = v + (int)gridDim.x;
-        const bool more = nv < total;
+        const int nt = tiles.next();
+        const bool more = nt >= 0;
         bool staged = false;
         if (more) {                                           // next tile's operands first, then this tile's output
-            setup(nv);
+            setup(nt);
             if (!guarded) { stage(0, 0); stage(1, 1); stage(2, 2); staged = true; }      // a guarded tile asks for its rows behind its poll, below
         }
         if (stamping) st[2] = __builtin_amdgcn_s_memrealtime();
@@ -507,8 +530,25 @@ __global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int
             soft_wait(g.p[pi].dep, m0 >> 8, g.p[pi].dep_need, g.p[pi].err);
             stage(0, 0); stage(1, 1); stage(2, 2);
         }
-        v = nv;
     }
+}
+
+template <bool AT, bool BT, int EPI, int TJ>
+__global__ __launch_bounds__(512) void gemm256p_kernel(const KGroup g, const int total, unsigned long long* const stamps) {
+    persistent_walk<AT, BT, EPI, TJ>(g, StrideTiles{(int)blockIdx.x, total}, stamps);
+    retire_mark(g);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Chain launch (vk_gemm_chain): a producer group (256 x 256 tiles, epilogue EPI_P) and the consumer group whose A operands are the
+// producers' outputs (256 x 192 tiles, epilogue EPI_C) in ONE persistent launch.  Every workgroup walks its producer tiles, signalling
+// row blocks (soft_signal), then its consumer tiles, each behind the poll of its row block (soft_wait): no launch boundary between the
+// two GEMMs, and the workgroups that run out of producer tiles early start on consumer tiles while the others finish.  Deadlock-free
+// under any residency: a waiting workgroup has no producer tile left, and a producer tile never waits.
+template <bool BT, int EPI_P, int EPI_C>
+__global__ __launch_bounds__(512) void gemm256c_kernel(const KGroup g, const int nprod, const int ncons, unsigned long long* const stamps) {
+    persistent_walk<false, BT, EPI_P, 4>(g, ProducerTiles{(int)blockIdx.x, nprod}, stamps);
+    persistent_walk<false, BT, EPI_C, 3>(g, ConsumerTiles{(int)(blockIdx.x >> 3), nprod, ncons}, stamps ? stamps + 16 : nullptr);
     retire_mark(g);
 }
 
@@ -555,6 +595,22 @@ static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s, boo
 #undef VK_CASE
 #undef VK_KERNEL_OF
     return check_launch("vk_gemm_grouped");
+}
+
+int launch_gemm256_chain(int layout, int epi_p, int epi_c, const KGroup& g, int nprod, int ncons, hipStream_t s) {
+    constexpr int LDS = 10 * HT;
+    const int ncu = (NUM_CU - g_reserved_cus.load(std::memory_order_relaxed)) & ~7;       // whole multiples of 8: the consumer deal assumes equal shares per XCD
+#define VK_CHAIN_CASE(BT_, P_, C_)                                                                                  \
+    if (layout == ((BT_) ? VK_NN : VK_NT) && epi_p == (P_) && epi_c == (C_)) {                                        \
+        auto k = gemm256c_kernel<BT_, P_, C_>;                                                                        \
+        static const hipError_t attr = hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); (void)attr; \
+        hipLaunchKernelGGL(k, dim3(ncu), dim3(512), LDS, s, g, nprod, ncons, g_stamps);                               \
+        return check_launch("vk_gemm_chain");                                                                         \
+    }
+    VK_CHAIN_CASE(false, VK_EPI_GELU, VK_EPI_BF16)          // FFN-up + GELU -> FFN-down          (encoders.py:486-501 -> 541-566)
+    VK_CHAIN_CASE(true, VK_EPI_MULR, VK_EPI_ADDR)           // FFN-down dgrad x gelu' -> FFN-up dgrad + residual gradient
+#undef VK_CHAIN_CASE
+    return set_error("vk_gemm_chain: layout %d with epilogues %d -> %d is not built (NT: GELU -> BF16, NN: MULR -> ADDR)", layout, epi_p, epi_c);
 }
 
 template <int KSPLIT>

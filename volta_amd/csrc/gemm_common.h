@@ -435,6 +435,8 @@ __device__ __forceinline__ bool split_combine(const KProb& P, int tile, f32x4 (&
 // study kernel (VK_STUDY builds only).  persistent: one workgroup per CU walks the tile list (NT / NN, no device-side row counts).
 constexpr int NUM_CU = 256;       // MI355X
 int launch_gemm256(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int variant, bool persistent, bool soft = false);
+// one persistent launch for a producer group (256 x 256 tiles) and the consumer group that reads its outputs (256 x 192 tiles)
+int launch_gemm256_chain(int layout, int epi_p, int epi_c, const KGroup& g, int nprod, int ncons, hipStream_t s);
 // 4-wave ring kernels (gemm4w.hip): bm = 256: 256 x 128 tiles, 72 KiB LDS, two workgroups per CU; bm = 128: 128 x 128 tiles, ring of 6 K-steps
 int launch_gemm4w(int layout, int epilogue, const KGroup& g, int total, hipStream_t s, int bm);
 

@@ -251,6 +251,12 @@ class StepEngine:
         # (profiles/r04_experiments.md: on gfx950 a barrier-less dispatch starts on an XCD only when that XCD's workgroups of the launch in
         # front are done, so there is no tail overlap to win, and the write-through hand-off costs what the shorter boundary saves)
         self.soft = os.environ.get("VK_SOFT", "0") == "1"
+        # FFN-up -> FFN-down as ONE persistent launch with row-block hand-off (vk_gemm_chain): "fwd" (default) the forward pair -- measured
+        # -0.08 ms per step (16.56 -> 16.48; per pair 205 -> 198 us from cold caches: the launch boundary goes, but the workgroups with three
+        # producer tiles set the pace, so the early finishers' head start does not shorten the launch); "all" also the backward pair
+        # (FFN-down dgrad x gelu' -> FFN-up dgrad): +0.12 ms, the weight gradients that need the first dgrad's output start a launch later;
+        # "0" two launches.  profiles/r04_experiments.md, profiles/r04_chain_stamps.txt
+        self.chain = os.environ.get("VK_CHAIN", "fwd")
         self.side_delay_us = int(os.environ.get("VK_SIDE_DELAY_US", "0"))
         # How a sub-layer's weight-gradient block (side stream) is started: "event" (default) -- the fork event of rounds 1-3; "gate" -- a
         # one-wave gate at the head of the block that the sub-layer's last dgrad releases as its first workgroup retires, no stream event
@@ -338,6 +344,11 @@ class StepEngine:
         arr = self.k((L.GemmProblem * len(probs))(*probs))
         plan_ops.append((L.OP_GEMM, layout | (geometry << 8), epi, len(probs), arr, None, None))
 
+    def gemm_chain(self, plan_ops, layout, epi_p, producers, epi_c, consumers):
+        ap = self.k((L.GemmProblem * len(producers))(*producers))
+        ac = self.k((L.GemmProblem * len(consumers))(*consumers))
+        plan_ops.append((L.OP_GEMM_CHAIN, layout, epi_p | (epi_c << 8), len(producers) | (len(consumers) << 8), ap, ac, None))
+
     def prob(self, A, B, Cout, M, N, K, lda, ldb, ldc, bias=None, R=None, ldr=0, C2=None, bias_grad=None, dyn=None, n_store=0):
         return L.GemmProblem(_addr(A), _addr(B), _addr(Cout), _addr(C2), _addr(bias), _addr(R), _addr(bias_grad), _addr(dyn),
                              M, N, K, lda, ldb, ldc, ldr, n_store)
@@ -367,14 +378,24 @@ class StepEngine:
     # is enqueued without the stream-order barrier; its tiles wait for row-block counters that the producer's tiles raise
     SOFT_ROWS = 1 << 16
 
-    def soft_counters(self, nrb):
+    def soft_counters(self, nrb, backward=False):
         """nrb int32 counters (one per 256-row block) out of the engine's counter arena, which one fill launch at the head of each command
         list zeroes; plus the address of the error word a timed-out poll raises."""
         cnt = self.bufs["soft_cnt"]
-        cur = self._soft_cur
-        assert cur + nrb <= cnt.numel(), "soft-boundary counter arena too small"
-        self._soft_cur = cur + _round_up(nrb, 32)            # a producer's counters on lines of their own
-        self._soft_zero.n[0] = 4 * (self._soft_cur - 32)     # the fill launch at the head of the forward list covers every counter handed out
+        n = _round_up(nrb, 32)                               # a producer's counters on lines of their own
+        assert self._soft_cur + n <= self._soft_cur_b, "hand-off counter arena too small"
+        if backward:
+            self._soft_cur_b -= n
+            cur = self._soft_cur_b
+            self._soft_zero_b.p[0] = cnt.data_ptr() + 4 * cur
+            self._soft_zero_b.n[0] = 4 * (self.SOFT_ROWS - cur)
+            if not getattr(self, "_soft_zero_b_listed", False):
+                self.bwd_pro.append((L.OP_GENERIC, 0, 0, 0, self._soft_zero_b, None, None))
+                self._soft_zero_b_listed = True
+        else:
+            cur = self._soft_cur
+            self._soft_cur = cur + n
+            self._soft_zero.n[0] = 4 * (self._soft_cur - 32)     # the fill launch at the head of the forward list covers every counter handed out
         return cnt.data_ptr() + 4 * cur, cnt.data_ptr()
 
     def soft_error(self):
@@ -488,12 +509,15 @@ class StepEngine:
         cfg, B, H = self.cfg, self.B, self.H
         st = self.st
         f = self.fwd.ops
-        if self.soft:
-            # row-block counters of the soft boundaries: word 0 is the error word (never cleared), the counters start on the next line and
-            # are zeroed by ONE fill launch per step, in front of everything (its length grows as _build hands counters out)
+        if self.soft or self.chain != "0":
+            # row-block counters of the hand-offs: word 0 is the error word (never cleared), the counters start on the next line and
+            # are zeroed by ONE fill launch per command list, in front of everything (its length grows as _build hands counters out);
+            # the forward's counters grow up from the start of the arena, the backward's down from its end
             self.bufs["soft_cnt"] = torch.zeros(self.SOFT_ROWS, dtype=torch.int32, device=self.dev)
             self._soft_cur = 32
+            self._soft_cur_b = self.SOFT_ROWS
             self._soft_zero = self.generic(L.FN_MEMSET, p=(self.bufs["soft_cnt"].data_ptr() + 128,), n=(0, 0))
+            self._soft_zero_b = self.generic(L.FN_MEMSET, p=(self.bufs["soft_cnt"].data_ptr() + 4 * self.SOFT_ROWS,), n=(0, 0))
             f.append((L.OP_GENERIC, 0, 0, 0, self._soft_zero, None, None))
         # per-step inputs (static staging copies are avoided: the few ops that read them are patched)
         self.masks = [self.buf("mask_t", (B, self.T), torch.float32), self.buf("mask_v", (B, self.Rv), torch.float32)]
@@ -1113,14 +1137,22 @@ class StepEngine:
             up = [self.prob(x_in[m], self.W(names[m]["up"] + ".weight"), h[m], self.st[m].M, Im[m], Hm[m], Hm[m], Hm[m], Im[m], bias=self.Pm(names[m]["up"] + ".bias"), C2=gp[m]) for m in ms]
             down = [self.prob(h[m], self.W(names[m]["down"] + ".weight"), d[m], self.st[m].M, Hm[m], Im[m], Im[m], Im[m], Hm[m], bias=self.Pm(names[m]["down"] + ".bias")) for m in ms]
             g_up = g_down = 0
-            if self.soft and self._soft_pair_ok([(self.st[m].M, Im[m], Hm[m]) for m in ms]):
+            pair_ok = self._soft_pair_ok([(self.st[m].M, Im[m], Hm[m]) for m in ms])
+            if self.chain != "0" and pair_ok:
+                for m, pu, pd in zip(ms, up, down):
+                    pu.sig, pu.err = self.soft_counters(self.st[m].M // 256)
+                    pd.dep, pd.err, pd.dep_need = pu.sig, pu.err, Im[m] // 256
+                self.gemm_chain(f, L.NT, L.EPI_GELU, up, L.EPI_BF16, down)
+                up = down = None
+            elif self.soft and pair_ok:
                 # FFN-down starts on the CUs FFN-up's last round leaves idle: row block r of h is handed over by counter (12 column tiles of 256)
                 for m, pu, pd in zip(ms, up, down):
                     pu.sig, pu.err = self.soft_counters(self.st[m].M // 256)
                     pd.dep, pd.err, pd.dep_need = pu.sig, pu.err, Im[m] // 256
                 g_up, g_down = 258, 259 | L.GEMM_SOFT_START
-            self.gemm(f, L.NT, L.EPI_GELU, up, geometry=g_up)
-            self.gemm(f, L.NT, L.EPI_BF16, down, geometry=g_down)
+            if up is not None:
+                self.gemm(f, L.NT, L.EPI_GELU, up, geometry=g_up)
+                self.gemm(f, L.NT, L.EPI_BF16, down, geometry=g_down)
         odrop, lnf = {}, []
         for m in ms:
             odrop[m] = self.drop(cfg.hidden_dropout_prob if m == 0 else cfg.v_hidden_dropout_prob)
@@ -1143,13 +1175,26 @@ class StepEngine:
             wtag = "" if Im[m] == self.I else "_%d" % Im[m]               # temporaries are shared by name: other widths get their own
             du[m] = self.tmp("du%d_%d%s" % (m, par, wtag), (self.st[m].M, Im[m]))
         self._ln_pair(b, L.OP_LN_BWD, lnb)
-        self.gemm(b, L.NN, L.EPI_MULR, [self.prob(dd[m], self.W(names[m]["down"] + ".weight"), du[m], self.st[m].M, Im[m], Hm[m], Hm[m], Im[m], Im[m], R=gp[m], ldr=Im[m]) for m in ms])
+        d1 = [self.prob(dd[m], self.W(names[m]["down"] + ".weight"), du[m], self.st[m].M, Im[m], Hm[m], Hm[m], Im[m], Im[m], R=gp[m], ldr=Im[m]) for m in ms]
+        d2 = [self.prob(du[m], self.W(names[m]["up"] + ".weight"), dxn[m], self.st[m].M, Hm[m], Im[m], Im[m], Hm[m], Hm[m], R=dz[m], ldr=Hm[m]) for m in ms]
+        chained = self.chain == "all" and not self.fp8 and self._soft_pair_ok([(self.st[m].M, Im[m], Hm[m]) for m in ms])
+        if chained:
+            # both dgrads in one launch; the weight gradients (which need du, the first one's output) start behind it
+            for m, p1, p2 in zip(ms, d1, d2):
+                p1.sig, p1.err = self.soft_counters(self.st[m].M // 256, backward=True)
+                p2.dep, p2.err, p2.dep_need = p1.sig, p1.err, Im[m] // 256
+            self.gemm_chain(b, L.NN, L.EPI_MULR, d1, L.EPI_ADDR, d2)
+        else:
+            self.gemm(b, L.NN, L.EPI_MULR, d1)
         # The weight gradients need dd, h, du and x_in: everything but the LAST dgrad's output.  Their side-stream block is listed in front of that
         # dgrad, so that it starts beside a GEMM (two MFMA-bound launches share the chip without loss) instead of beside the LayerNorm backward
         # that follows, which it used to keep waiting for CUs (profiles/r03_experiments.md: 17.00 / 16.94 -> 16.52 / 16.54 ms per step).
+        gate_mode, self.side_gate = self.side_gate, self.side_gate and not chained      # behind a chain the block starts on the fork event
         self._wgrad(b, ms, shared, [lambda m: (dd[m], h[m], self.G(names[m]["down"] + ".weight"), self.G(names[m]["down"] + ".bias"), Hm[m], Im[m], Hm[m], Im[m]),
                                     lambda m: (du[m], x_in[m], self.G(names[m]["up"] + ".weight"), self.G(names[m]["up"] + ".bias"), Im[m], Hm[m], Im[m], Hm[m])])
-        self.gemm(b, L.NN, L.EPI_ADDR, self.retire_on([self.prob(du[m], self.W(names[m]["up"] + ".weight"), dxn[m], self.st[m].M, Hm[m], Im[m], Im[m], Hm[m], Hm[m], R=dz[m], ldr=Hm[m]) for m in ms]))
+        self.side_gate = gate_mode
+        if not chained:
+            self.gemm(b, L.NN, L.EPI_ADDR, self.retire_on(d2))
         return b
 
     def _wgrad(self, b, ms, shared, specs):

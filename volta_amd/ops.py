@@ -96,6 +96,12 @@ def gemm_grouped(layout, epilogue, problems, geometry=None):
     check(L.lib.vk_gemm_grouped_ex(layout, epilogue, arr, len(problems), default_geometry if geometry is None else geometry, stream_ptr()))
 
 
+def gemm_chain(layout, epi_p, producers, epi_c, consumers):
+    """vk_gemm_chain: producers (256 x 256 tiles, `sig`) and the consumers of their outputs (256 x 192 tiles, `dep`) in one persistent launch."""
+    ap, ac = (L.GemmProblem * len(producers))(*producers), (L.GemmProblem * len(consumers))(*consumers)
+    check(L.lib.vk_gemm_chain(layout, epi_p, ap, len(producers), epi_c, ac, len(consumers), stream_ptr()))
+
+
 def cast_f32_bf16(src, dst):
     assert src.dtype == torch.float32 and dst.dtype == torch.bfloat16 and src.numel() == dst.numel()
     check(L.lib.vk_cast_f32_bf16(ptr(src), ptr(dst), src.numel(), stream_ptr()))
