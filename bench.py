@@ -400,17 +400,17 @@ def main():
                 "whole_step": {"achieved": whole["achieved"], "frac": whole["frac"], "scope": whole["scope"]}}
             out["kernel_ms_per_step"] = {k: round(v, 3) for k, v in sorted(kinds.items(), key=lambda kv: -kv[1])}
             # HBM traffic of the dominant kernel: PMC counters cannot be read from inside the process, so the figure is the
-            # one of the committed rocprofv3 --pmc passes over this same command (profiles/r03_pmc_hbm_traffic.md)
+            # one of the committed rocprofv3 --pmc passes over this same command (profiles/r04_pmc_hbm_traffic.md)
             # -- and only while that pass describes THIS library: the summary carries a fingerprint of the kernel sources it profiled
-            pmc = os.path.join(ROOT, "profiles", "r03_pmc_summary.json")
+            pmc = os.path.join(ROOT, "profiles", "r04_pmc_summary.json")
             if os.path.exists(pmc) and a.config == "ctrl_vilbert_base" and a.batch == 256 and a.dtype == "bf16":
                 pm = json.load(open(pmc))
                 if pm.get("source_fingerprint") == source_fingerprint():
                     out["roofline"]["traffic"] = pm["hbm_bytes_per_launch"]
-                    out["roofline"]["traffic_note"] = ("HBM bytes per GEMM launch (avg of %d launches/step), FETCH_SIZE x2 + WRITE_SIZE from profiles/r03_pmc_summary.json "
+                    out["roofline"]["traffic_note"] = ("HBM bytes per GEMM launch (avg of %d launches/step), FETCH_SIZE x2 + WRITE_SIZE from profiles/r04_pmc_summary.json "
                                                        "(rocprofv3 --pmc passes over this command; kernel sources unchanged since)" % pm["launches_per_step"])
                 else:
-                    out["roofline"]["traffic_note"] = "profiles/r03_pmc_summary.json was collected on different kernel sources: traffic withheld (re-run tools/collect_profiles.sh)"
+                    out["roofline"]["traffic_note"] = "profiles/r04_pmc_summary.json was collected on different kernel sources: traffic withheld (re-run tools/collect_profiles.sh)"
         if world == 1 and not a.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(a.config, a.seq_len, a.regions)

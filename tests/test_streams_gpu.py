@@ -26,7 +26,9 @@ def test_gate_and_flag_order_two_streams_without_an_event():
     """vk_store_u64 on one stream releases vk_gate_value on another; a gate whose flag never comes gives up and raises the error word."""
     import ctypes as C
     from volta_amd import _lib as L
-    a, b = torch.cuda.Stream(), torch.cuda.Stream()
+    from volta_amd import streams as S
+    a = torch.cuda.Stream()
+    b = S.independent_stream(avoid=[a])          # a gate on the hardware queue of the stream that releases it would wait for its own releaser
     words = torch.zeros(4, dtype=torch.int64, device="cuda")
     err = torch.zeros(1, dtype=torch.int32, device="cuda")
     out = torch.zeros(1, device="cuda")

@@ -52,6 +52,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(vk_embed_bwd_args a)
     __shared__ float red[4][4][NCH * 256];
     __shared__ int64_t id_s[32];
     __shared__ int ty_s[32], row_s[32];
+    __shared__ int64_t ps_s[32];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nb = a.M / a.T;                                  // samples
     if (threadIdx.x < 32) {
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(vk_embed_bwd_args a)
         row_s[threadIdx.x] = row;
         id_s[threadIdx.x] = row >= 0 ? clampi(a.ids[row], a.V) : -1;
         ty_s[threadIdx.x] = (row >= 0 && a.type_ids) ? (int)clampi(a.type_ids[row], a.n_types) : 0;
+        ps_s[threadIdx.x] = (row >= 0 && a.pos_ids) ? clampi(a.pos_ids[row], a.P) : -1;
     }
     __syncthreads();
     float ta[4][NCH][4];
@@ -77,16 +79,51 @@ __global__ __launch_bounds__(256) void embed_scatter_kernel(vk_embed_bwd_args a)
         const int64_t id = id_s[r0];
         bool first = true;                                     // wave-uniform: is this the workgroup's first row with this id?
         for (int q = 0; q < r0; ++q) first &= id_s[q] != id;
-        const int64_t ps = a.pos_ids ? clampi(a.pos_ids[row], a.P) : -1;
-        if (ps >= 0) {                                         // explicit positions (VL-BERT): per row, as before
+        const int64_t ps = ps_s[r0];
+        bool firstp = ps >= 0;                                 // wave-uniform: the workgroup's first row with this position id
+        for (int q = 0; q < r0; ++q) firstp &= ps_s[q] != ps;
+        if (firstp) {
+            // explicit positions (VL-BERT): the 32 rows of a workgroup are 32 samples at ONE sequence position, and VL-BERT gives every region
+            // of every sample the same position id -- one atomic per row made 25 600 rows queue on one table row (1.4 ms at 100 regions,
+            // profiles/r04_vlbert_r100_kernel_stats.md); the first row of an id sums the workgroup's duplicates, as for the word table
+            float pacc[NCH][4];
+#pragma unroll
+            for (int j = 0; j < NCH; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) pacc[j][r] = 0.f;
+            unsigned long long dupp = __ballot(lane < 32 && lane >= r0 && ps_s[lane & 31] == ps && row_s[lane & 31] >= 0);
+            while (dupp) {
+                int qs[4], n = 0;
+                for (; n < 4 && dupp; ++n) { qs[n] = __builtin_ctzll(dupp); dupp &= dupp - 1; }
+                float v[4][NCH][4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (u < n) {
+#pragma unroll
+                        for (int j = 0; j < NCH; ++j) {
+                            const int c = j * 256 + lane * 4;
+                            if (c < a.H) ld4((const uint16_t*)a.dz + (size_t)row_s[qs[u]] * a.H + c, v[u][j]);
+                        }
+                    }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (u < n) {
+#pragma unroll
+                        for (int j = 0; j < NCH; ++j) {
+                            const int c = j * 256 + lane * 4;
+                            if (c < a.H) {
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) pacc[j][r] += v[u][j][r];
+                            }
+                        }
+                    }
+            }
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
                 const int c = j * 256 + lane * 4;
                 if (c < a.H) {
-                    float v[4];
-                    ld4((const uint16_t*)a.dz + (size_t)row * a.H + c, v);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) atomicAdd(a.dpos + (size_t)ps * a.H + c + r, v[r]);
+                    for (int r = 0; r < 4; ++r) atomicAdd(a.dpos + (size_t)ps * a.H + c + r, pacc[j][r]);
                 }
             }
         }

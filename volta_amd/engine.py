@@ -264,6 +264,13 @@ class StepEngine:
         # 0.1-0.2 ms per step slower than the event form and no cure for the slow steps it was built against (those came from a helper
         # stream on the compute stream's pipe: volta_amd/streams.py, profiles/r04_experiments.md).  Kept as a switch.
         self.side_gate = os.environ.get("VK_SIDE_START", "event") == "gate"
+        if self.side_gate:
+            # a gate on the hardware queue of the stream that releases it would wait for its own releaser (until its timeout): only with the side
+            # stream on a queue of its own
+            from . import streams as S
+            own, side = S.engine_streams()
+            if S.shares_queue(own, side) or S.shares_queue(side, own):
+                self.side_gate = False
         dev = arena.device
         self.dev = dev
         H, Hv = cfg.hidden_size, cfg.v_hidden_size
