@@ -331,7 +331,9 @@ def main():
         "host_note": "host_work = one step issued into an empty queue (the host's own cost); host_issue = wall time of the issuing loop, throttled "
                      "by queue back-pressure to the GPU's pace",
         **({"rehearsal": "all ranks share cuda:0 over gloo: timings are meaningless"} if shared else {}),
-        "losses_last_step": [float(x.detach()) for x in losses]})
+        "losses_last_step": [float(x.detach()) for x in losses],
+        # 0 = no guarded tile of a chained GEMM launch ever gave up waiting for its row block (engine.soft_error(); a wrong schedule would show here, not as a hang)
+        "handoff_errors": model._last[0].soft_error()})
     if rank == 0:
         print("[bench] timed region done: %.3f ms/step, %.1f pairs/s" % (ms, pairs_s), file=sys.stderr, flush=True)
         if gflop is not None:

@@ -263,6 +263,10 @@ typedef struct vk_attn_bwd_args {
 int vk_gated_attn_fwd(const vk_attn_args* a, vk_stream_t s);
 /* `a` must be the forward call's arguments (ctx and lse now inputs). */
 int vk_gated_attn_bwd(const vk_attn_args* a, const vk_attn_bwd_args* b, vk_stream_t s);
+/* Host arithmetic, no device work: bytes of LDS the launch would ask for per workgroup when it runs on the generic kernels (rows beyond
+ * the MFMA tiles, head sizes 32 / 96, attention maps), 0 when the MFMA kernels serve it.  More than 160 KiB cannot run: a planner checks
+ * BEFORE the first step (the backward needs about twice the forward's: ~491 keys at head size 64, ~258 at 128). */
+size_t vk_gated_attn_lds_bytes(const vk_attn_args* a, int backward);
 
 /* ------------------------------------------------------------------------------------------------
  * Embeddings.  vk_embed_sum_fwd replaces the three nn.Embedding lookups and their sum in

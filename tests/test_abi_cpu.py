@@ -118,3 +118,23 @@ def test_schedule_helpers_match_oracle():
         assert abs(opt.param_groups[0]["lr"] - R.warmup_linear(step, 3, 10)) < 1e-12
         opt.step()
         sch.step()
+
+
+def test_generic_attention_lds_need_is_known_before_the_first_launch():
+    """Rows beyond the MFMA attention tiles run on the generic kernels, whose backward keeps two row images of both modalities in LDS: the
+    planner asks vk_gated_attn_lds_bytes (host arithmetic) and refuses a plan the backward could not launch (492-512 rows built
+    fine and failed at the first backward)."""
+    import ctypes as C
+    from volta_amd import _lib as L
+    aa = L.AttnArgs()
+    aa.B, aa.nh, aa.dh, aa.scale = 2, 12, 64, 0.125
+    for i in range(2):
+        for j in range(2):
+            aa.gate[i][j] = 1
+    aa.L[0], aa.L[1] = 20, 37
+    assert L.lib.vk_gated_attn_lds_bytes(C.byref(aa), 1) == 0            # the MFMA kernels serve the pre-training shapes
+    aa.L[0], aa.L[1] = 80, 301
+    f, b = L.lib.vk_gated_attn_lds_bytes(C.byref(aa), 0), L.lib.vk_gated_attn_lds_bytes(C.byref(aa), 1)
+    assert 0 < f < b <= 160 * 1024
+    aa.L[0], aa.L[1] = 80, 420                                            # 500 keys: the forward fits, the backward does not
+    assert L.lib.vk_gated_attn_lds_bytes(C.byref(aa), 0) <= 160 * 1024 < L.lib.vk_gated_attn_lds_bytes(C.byref(aa), 1)

@@ -185,6 +185,7 @@ _sig("vk_gemm_chain", C.c_int, C.c_int, C.c_int, C.POINTER(GemmProblem), C.c_int
 _sig("vk_gemm_split_workspace_bytes", C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int))
 _sig("vk_gated_attn_fwd", C.c_int, C.POINTER(AttnArgs), c_p)
 _sig("vk_gated_attn_bwd", C.c_int, C.POINTER(AttnArgs), C.POINTER(AttnBwdArgs), c_p)
+_sig("vk_gated_attn_lds_bytes", C.c_size_t, C.POINTER(AttnArgs), C.c_int)
 _sig("vk_ln_fwd", C.c_int, C.POINTER(LnArgs), c_p)
 _sig("vk_ln_bwd_partial_rows", C.c_int, C.c_int)
 _sig("vk_ln_bwd", C.c_int, C.POINTER(LnBwdArgs), c_p)
@@ -265,7 +266,7 @@ _sig("vk_side_enable", None, C.c_int)
 _sig("vk_side_stream", c_p, c_p)
 
 EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_cast_f32_bf16", "vk_gemm_grouped", "vk_gemm_grouped_ex", "vk_gemm_chain", "vk_gemm_split_workspace_bytes", "vk_gemm_fp8_grouped", "vk_quant_rows_fp8", "vk_cast_bf16_fp8",
-           "vk_ln_fwd", "vk_ln_fwd_pair", "vk_ln_bwd_partial_rows", "vk_ln_bwd", "vk_ln_bwd_pair", "vk_ln_bwd_finalize", "vk_gated_attn_fwd", "vk_gated_attn_bwd",
+           "vk_ln_fwd", "vk_ln_fwd_pair", "vk_ln_bwd_partial_rows", "vk_ln_bwd", "vk_ln_bwd_pair", "vk_ln_bwd_finalize", "vk_gated_attn_fwd", "vk_gated_attn_bwd", "vk_gated_attn_lds_bytes",
            "vk_embed_sum_fwd", "vk_embed_sum_bwd", "vk_rows32", "vk_loc_linear_fwd", "vk_loc_linear_bwd",
            "vk_add_dropout", "vk_colsum_bf16", "vk_vlbert_prep_fwd", "vk_vlbert_maskgrad", "vk_rowgroup_sum_bf16",
            "vk_relu_bwd_bf16", "vk_copy_async", "vk_select_rows", "vk_gather_rows", "vk_scatter_rows_add", "vk_xent_fwd",

@@ -594,6 +594,13 @@ static bool attn_mfma_ok(const vk_attn_args* a) {
     return vk::bwd_fits(TP, RP, 128);           // forward and backward of one sub-layer take the same path
 }
 
+namespace vk { size_t attn_generic_lds(const vk_attn_args* a, bool bwd); }
+
+extern "C" size_t vk_gated_attn_lds_bytes(const vk_attn_args* a, int backward) {
+    if (!a || attn_mfma_ok(a)) return 0;
+    return vk::attn_generic_lds(a, backward != 0);
+}
+
 extern "C" int vk_gated_attn_fwd(const vk_attn_args* a, vk_stream_t stream) {
     using namespace vk;
     if (!attn_mfma_ok(a)) return attn_generic(a, nullptr, stream);

@@ -9,7 +9,7 @@
 // 306 regions of GuessWhatPointing (config_tasks/all_tasks.yml:59-70,95-105,306-335; the reference's attention has no length limit,
 // encoders.py:258-340) -- come here at any head size: a query row's keys are held NS x 64 at a time in registers (NS <= 8: 512 keys of
 // both modalities together), and the backward runs in two phases that each keep only two row images in LDS (K, V for dQ; Q, dO for
-// dK, dV), so that 64-wide heads fit up to ~540 rows in total.
+// dK, dV), so that 64-wide heads fit up to ~540 rows in total in the forward and ~491 in the backward (vk_gated_attn_lds_bytes).
 #include "common.h"
 #include "../../include/volta_hip.h"
 #include "util.h"
@@ -327,6 +327,24 @@ static int g_launch(const AttnG& k, bool bwd, hipStream_t s) {
     if (need <= 192) return g_launch_ns<D, 3>(k, bwd, s);
     if (need <= 320) return g_launch_ns<D, 5>(k, bwd, s);
     return g_launch_ns<D, 8>(k, bwd, s);
+}
+
+// LDS bytes the generic kernels would ask for (host arithmetic for vk_gated_attn_lds_bytes); 0 when no key is visible
+size_t attn_generic_lds(const vk_attn_args* a, bool bwd) {
+    AttnG k;
+    for (int m = 0; m < 2; ++m) {
+        const bool qa = a->gate[m][0] || a->gate[m][1], ka = a->gate[0][m] || a->gate[1][m];
+        k.L[m] = (qa || ka) ? a->L[m] : 0;
+        for (int j = 0; j < 2; ++j) k.gate[m][j] = a->gate[m][j];
+    }
+    int need = 0;
+    for (int m = 0; m < 2; ++m) {
+        const int nq = (k.gate[m][0] ? k.L[0] : 0) + (k.gate[m][1] ? k.L[1] : 0), nk = (k.gate[0][m] ? k.L[0] : 0) + (k.gate[1][m] ? k.L[1] : 0);
+        need = need > nq ? need : nq;
+        need = need > nk ? need : nk;
+    }
+    const int NS = need <= 192 ? 3 : need <= 320 ? 5 : 8;
+    return g_lds_bytes(k, a->dh ? a->dh : 64, NS, bwd);
 }
 
 // called by vk_gated_attn_fwd / _bwd (attention.hip) for what its MFMA kernels do not hold: head sizes other than 64 / 128, rows beyond their tiles

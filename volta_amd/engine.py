@@ -361,7 +361,10 @@ class StepEngine:
                              M, N, K, lda, ldb, ldc, ldr, n_store)
 
     # ---- split accumulations (include/volta_hip.h, vk_gemm_problem::ws): K-slices of one product in one launch, summed by the last arriver
-    SPLIT_WS_CAP = 768 << 20         # bytes of partial-tile workspace per stream (launches on one stream are ordered: they share it)
+    # bytes of partial-tile workspace per stream (launches on one stream are ordered: they share it).  Sized by the first request -- the only user
+    # is the image projection's weight gradient, one product per launch: nparts x tiles x 320 KiB = 84 MB for [1024 x 2048] at B = 256 --
+    # instead of a fixed 768 MiB per cached engine; VK_SPLIT_WS_MB overrides
+    SPLIT_WS_MIN = 32 << 20
 
     def _split_alloc(self, tag, layout, M, N, nparts, geometry):
         """(ws address, cnt address) for one split accumulation of the launch being built on stream `tag` ("main" / "side")."""
@@ -369,13 +372,18 @@ class StepEngine:
         nbytes = L.lib.vk_gemm_split_workspace_bytes(layout, M, N, nparts, geometry, C.byref(tiles))
         assert nbytes > 0 and tiles.value > 0, (layout, M, N, nparts, geometry)
         aside, self._aside = getattr(self, "_aside", ""), ""          # the arenas belong to a stream, not to a block of ops
-        ws = self.tmp("split_ws_" + tag, (self.SPLIT_WS_CAP,), torch.uint8)
+        if "split_ws_" + tag not in self.bufs:
+            mb = os.environ.get("VK_SPLIT_WS_MB")
+            cap = (int(mb) << 20) if mb else max(self.SPLIT_WS_MIN, _round_up(int(nbytes * 1.25), 1 << 20))
+            self.bufs["split_ws_" + tag] = torch.empty(cap, dtype=torch.uint8, device=self.dev)
+        ws = self.bufs["split_ws_" + tag]
         self._aside = aside
         if "split_cnt_" + tag not in self.bufs:
             self.bufs["split_cnt_" + tag] = torch.zeros(1 << 16, dtype=torch.int32, device=self.dev)      # zero once: every launch leaves them zero
         cnt = self.bufs["split_cnt_" + tag]
         cur = self.__dict__.setdefault("_split_cur", {}).setdefault(tag, [0, 0])
-        assert cur[0] + nbytes <= self.SPLIT_WS_CAP and cur[1] + tiles.value <= cnt.numel(), "split workspace too small"
+        if cur[0] + nbytes > ws.numel() or cur[1] + tiles.value > cnt.numel():
+            raise RuntimeError("split-accumulation workspace too small (%d + %d of %d bytes): set VK_SPLIT_WS_MB" % (cur[0], nbytes, ws.numel()))
         out = (ws.data_ptr() + cur[0], cnt.data_ptr() + 4 * cur[1])
         cur[0] += _round_up(nbytes, 256)
         cur[1] += tiles.value
@@ -1039,6 +1047,13 @@ class StepEngine:
                             aa.probs[i][j] = pb[(i, j)].data_ptr()
                 self.attn_map_info.append(dict(n=n, probs=pb, qkv={m: qkv[m] for m in mq}, Ha={m: Ha[m] for m in mq}, nh=nhm[m0], dh=dh[m0]))
             self.k(aa)
+            # rows the generic kernels cannot hold in LDS fail HERE, when the plan is built, not at the first backward launch (their backward
+            # keeps two row images of both modalities: ~491 keys at head size 64, ~258 at 128, less than the forward's 512)
+            for bwd_pass in (0, 1):
+                need = L.lib.vk_gated_attn_lds_bytes(C.byref(aa), bwd_pass)
+                if need > 160 * 1024:
+                    raise NotImplementedError("attention sub-layer %d: %d + %d rows at head size %d need %d bytes of LDS in the %s pass (160 KiB per workgroup)"
+                                              % (n, self.st[0].L, self.st[1].L, dh[m0], need, "backward" if bwd_pass else "forward"))
             f.append((L.OP_ATTN_FWD, 0, 0, 0, aa, None, None))
             attn.append((aa, mq, gl))
         self.gemm(f, L.NT, L.EPI_BF16, [self.prob(ctx[m], self.W(names[m]["o"] + ".weight"), d[m], self.st[m].M, Hm[m], Ha[m], Ha[m], Ha[m], Hm[m], bias=self.Pm(names[m]["o"] + ".bias")) for m in ms])
