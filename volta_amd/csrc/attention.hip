@@ -561,6 +561,9 @@ static int launch_bwd(const AttnK& k, int ntasks, hipStream_t s) {
         auto kern = attn_bwd_kernel<TP, RP, 2, DHT>;
         static const hipError_t attr = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds); (void)attr;      // once per process, thread-safe
         int waves = g_attn_bwd_waves < 4 ? 4 : (ntasks > g_attn_bwd_waves ? g_attn_bwd_waves : (ntasks < 4 ? 4 : ntasks));      // staging is sized for >= 256 threads
+        // images so large that only ONE workgroup fits a CU (VL-BERT at 100 regions: 32 + 128 padded rows = 82 KiB): four waves would leave half
+        // the CU's wave slots empty (508 us per launch, profiles/r04_vlbert_r100_kernel_stats.md) -- give the workgroup all eight
+        if (2 * lds > 160 * 1024) waves = ntasks >= 8 ? 8 : (ntasks < 4 ? 4 : ntasks);
         hipLaunchKernelGGL(kern, dim3(k.B * k.nh), dim3(64 * waves), lds, s, k);
     }
     return check_launch("vk_gated_attn_bwd");

@@ -75,12 +75,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // holds element K-1 of the LAST row would count as out of range and read as zero (found with the one-column region-logit head: K = 1 lost
 // the whole last row).  The row is extended to an even element count inside its leading dimension; the extra element is a pad column, which
 // is zero by the ragged-K contract (lda padded to a multiple of 64, pad written as 0) or meets an out-of-range (zero) row of the other operand.
-#ifndef VK_WT_GEMM
-#define VK_WT_GEMM 0
-#endif
-#ifndef VK_WT_SLAB
-#define VK_WT_SLAB 0
-#endif
 // 16-byte write-through (sc1) store: the line goes to the memory side at once and is dropped from the XCD's L2, so it is not among the
 // dirty lines the end-of-kernel release has to write back (MI355X_MICROARCH.md, "stores of each flavour" / boundary row)
 __device__ __forceinline__ void store16_wt(void* p, u32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
@@ -228,26 +222,12 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
                     if ((RPI * CPR < 64 && rr0 >= RPI) || ((RPH % RPI) && row >= RPH)) continue;
                     const uint32_t a = row * PITCH + ((ch ^ (row & SWZ)) << 4);
                     const size_t g = ((size_t)(mrow0 + row) * ldc + (size_t)n_base) * ES + (size_t)ch * 16;
-                    if (AT && EPI == VK_EPI_F32) {
-#if VK_WT_SLAB
-                        store16_wt(Cp + g, *(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a));
-#else
-                        __builtin_nontemporal_store(*(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a), (u32x4*)(Cp + g));      // weight-gradient slab: read once, by the tail launch
-#endif
-                    }
-#if VK_WT_GEMM
-                    else store16_wt(Cp + g, *(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a));
-#else
-                    else if (wt) store16_wt(Cp + g, *(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a));      // handed to the next launch by counter (soft_signal)
-                    else *(u32x4*)(Cp + g) = *(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a);
-#endif
+                    if (AT && EPI == VK_EPI_F32) __builtin_nontemporal_store(*(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a), (u32x4*)(Cp + g));      // weight-gradient slab: read once, by the tail launch
+                    else if (wt) store16_wt(Cp + g, *(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a));      // handed to a consumer tile by counter (soft_signal): write-through
+                    else *(u32x4*)(Cp + g) = *(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a);      // (write-through for EVERY output measured neutral: profiles/r04_experiments.md)
                     // gelu'(u) is read again only by the backward pass: stored non-temporally so that it does not push the activation beside
                     // it -- the next GEMM's A operand -- out of the Infinity Cache
-#if VK_WT_GEMM > 1
-                    if (EPI == VK_EPI_GELU) store16_wt(C2p + g, *(const u32x4 VK_LDS*)(uintptr_t)(img2 + a));
-#else
                     if (EPI == VK_EPI_GELU) __builtin_nontemporal_store(*(const u32x4 VK_LDS*)(uintptr_t)(img2 + a), (u32x4*)(C2p + g));
-#endif
                 }
             }
         }
