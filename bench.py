@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--serial", action="store_true", help="run the side-stream blocks (weight gradients) inline: per-kernel profiles without concurrency")
+    ap.add_argument("--no-dropout", action="store_true", help="DIAGNOSTIC, not the BASELINE workload (the line says so): every dropout probability 0 -- what the counter-based mask generation costs the step")
     ap.add_argument("--dump-ops", default=None, help="write the per-op timing table of the profiled steps to this file")
     return ap.parse_args()
 
@@ -194,8 +195,8 @@ def result_line(a, world, elapsed, t_issue, extra):
     out = {"metric": "image-text pairs/sec, %s pretrain step" % a.config, "value": pairs_s, "unit": "image-text pairs/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-           "config": {"workload": "%s pretrain step (fwd+bwd+clip+AdamW%s), per-GPU batch %d, T=%d, %d regions (+1 global), objective 1, dropout on"
-                      % (a.config, "+allreduce" if world > 1 else "", a.batch, a.seq_len, a.regions),
+           "config": {"workload": "%s pretrain step (fwd+bwd+clip+AdamW%s), per-GPU batch %d, T=%d, %d regions (+1 global), objective 1, dropout %s"
+                      % (a.config, "+allreduce" if world > 1 else "", a.batch, a.seq_len, a.regions, "OFF (diagnostic run, not the BASELINE workload)" if a.no_dropout else "on"),
                       "global_batch": a.batch * world, "seq_len": a.seq_len, "regions": a.regions, "parallelism": "dp%d" % world},
            "host_issue_ms_per_step": t_issue * 1e3 / a.steps}
     out.update(extra)
@@ -271,6 +272,9 @@ def main():
         L.lib.vk_side_enable(0)
 
     cfg = BertConfig.from_json_file(os.path.join(ROOT, "config", a.config + ".json"))
+    if a.no_dropout:
+        for k in ("hidden_dropout_prob", "attention_probs_dropout_prob", "v_hidden_dropout_prob", "v_attention_probs_dropout_prob"):
+            setattr(cfg, k, 0.0)
     torch.manual_seed(1234)
     model = BertForVLPreTraining(cfg).cuda()
     model.train()
