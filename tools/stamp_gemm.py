@@ -35,8 +35,14 @@ def main():
     big_b = torch.empty_like(big_a)
     for name, layout, epi, N, K in (("ffn-up + GELU (f54)", L.NT, L.EPI_GELU, 3072, 768), ("qkv (f57)", L.NT, L.EPI_BF16, 2304, 768),
                                     ("ffn-down dgrad x gelu' (b30)", L.NN, L.EPI_MULR, 3072, 768), ("ffn-down (f55, one round)", L.NT, L.EPI_BF16, 768, 3072)):
+        if os.environ.get("STAMP_ONLY") and os.environ["STAMP_ONLY"] not in name:
+            continue
         arr, keep = group(layout, epi, N, K)
-        for geo_name, geo in (("persistent", L.GEMM_PERSISTENT), ("one tile per wg", L.GEMM_ONE_TILE_PER_WG)):
+        variants = [("persistent", L.GEMM_PERSISTENT, 0), ("one tile per wg", L.GEMM_ONE_TILE_PER_WG, 0)]
+        if os.environ.get("STAMP_DESYNC"):        # every other workgroup of an XCD starts N us late: are lockstep epilogues what costs?
+            variants.insert(1, ("persistent, odd wgs %s us late" % os.environ["STAMP_DESYNC"], L.GEMM_PERSISTENT, int(os.environ["STAMP_DESYNC"]) * 100))
+        for geo_name, geo, desync in variants:
+            L.lib.vk_gemm_set_desync(desync)
             for cold in (False, True):
                 call = lambda: L.check(L.lib.vk_gemm_grouped_ex(layout, epi, arr, 2, geo, ops.stream_ptr()))
                 ts = []
@@ -50,19 +56,21 @@ def main():
                     torch.cuda.synchronize()
                     ts.append(e0.elapsed_time(e1) * 1e3)
                 L.lib.vk_gemm_set_stamp_buffer(None)
-                line = "%-30s %-16s %-5s launch %.1f us" % (name, geo_name, "cold" if cold else "hot", sorted(ts)[len(ts) // 2])
+                line = "%-30s %-30s %-5s launch %.1f us" % (name, geo_name, "cold" if cold else "hot", sorted(ts)[len(ts) // 2])
                 if geo == L.GEMM_PERSISTENT:
                     st = stamps.view(256, 8, 4).cpu().double() / 100.0          # us
                     t_first = st[:, 0, 0][st[:, 0, 0] > 0].min()
-                    for ti in range(4):
-                        s = st[:, ti]
+                    on_time = ((torch.arange(256) >> 3) & 1) == 0
+                    halves = (("", slice(None)),) if not desync else ((" [on-time]", on_time), (" [late]", ~on_time))
+                    for ti, (tag, sel) in ((ti, h) for ti in range(4) for h in halves):
+                        s = st[sel][:, ti]
                         live = s[:, 3] > 0
                         if int(live.sum()) == 0:
                             continue
                         s = s[live]
                         seg = [float((s[:, 1] - s[:, 0]).median()), float((s[:, 2] - s[:, 1]).median()), float((s[:, 3] - s[:, 2]).median())]
-                        line += " | tile %d (%d wgs): K loop %.1f drain+next %.1f epilogue %.1f, ends at %.1f" % (
-                            ti, int(live.sum()), seg[0], seg[1], seg[2], float((s[:, 3] - t_first).median()))
+                        line += " | tile %d%s (%d wgs): K loop %.1f drain+next %.1f epilogue %.1f, ends at %.1f" % (
+                            ti, tag, int(live.sum()), seg[0], seg[1], seg[2], float((s[:, 3] - t_first).median()))
                 print(line, flush=True)
 
 

@@ -268,6 +268,7 @@ __device__ __forceinline__ bf16x8 frag_strip(uint32_t strip, int r0, int lane) {
 
 #ifdef VK_STUDY
 __device__ unsigned long long* g_kstamps = nullptr;      // tools/stamp_soft.py: start / end s_memrealtime of every workgroup of the one-tile kernel
+__device__ int g_desync_ticks = 0;                       // tools/stamp_gemm.py: every other workgroup of an XCD starts this many 10 ns ticks late (are lockstep epilogues the cost?)
 #endif
 
 // TJ = 16-column tiles per wave along N: 4 -> 256 x 256 tile, 3 -> 256 x 192 (N = 768 / 2304 split into 4 / 12 column
@@ -467,6 +468,12 @@ __device__ __forceinline__ void persistent_walk(const KGroup& g, Tiles tiles, un
 
     int tile = tiles.next();
     if (tile < 0) return;
+#ifdef VK_STUDY
+    if (g_desync_ticks > 0 && ((blockIdx.x >> 3) & 1)) {
+        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)g_desync_ticks) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     setup(tile);
     if (guarded) soft_wait(g.p[pi].dep, m0 >> 8, g.p[pi].dep_need, g.p[pi].err);
     stage(0, 0); stage(1, 1); stage(2, 2);
@@ -643,4 +650,5 @@ extern "C" int vk_gemm_reserve_cus(int n) {
 #ifdef VK_STUDY
 extern "C" void vk_gemm_set_stamp_buffer(void* p) { vk::g_stamps = (unsigned long long*)p; }
 extern "C" int vk_gemm_set_kstamp_buffer(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(vk::g_kstamps), &p, sizeof(p)); }
+extern "C" int vk_gemm_set_desync(int ticks) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(vk::g_desync_ticks), &ticks, sizeof(ticks)); }
 #endif

@@ -108,6 +108,9 @@ __device__ __forceinline__ void soft_signal(int32_t* sig, int rb) {
 
 __device__ __forceinline__ int even_up(int K, int ld) { const int e = (K + 1) & ~1; return e < ld ? e : ld; }
 
+#ifndef VK_EPI_ABLATE      // A/B builds (tools/runs): 1 = GELU epilogue without the gelu' stores, 2 = with trivial arithmetic, 3 = both
+#define VK_EPI_ABLATE 0
+#endif
 template <bool AT, int EPI, int TI, int TJ, int REGION = 16384>       // REGION: bytes of the wave-private LDS staging region
 __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][TJ], f32x4 (&accb)[TI], bool do_bias_grad,
                                               int m_base, int n_base, int M, int lane, uint32_t lds_region = 0) {
@@ -195,6 +198,7 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     if (EPI == VK_EPI_BF16) o[r] = v[r];
+                    else if (EPI == VK_EPI_GELU && (VK_EPI_ABLATE & 2)) { o[r] = v[r]; o2[r] = 0.5f * v[r]; }
                     else if (EPI == VK_EPI_GELU) { gelu_both(v[r], o[r], o2[r]); }
                     else if (EPI == VK_EPI_MULR) o[r] = v[r] * w[r];
                     else if (EPI == VK_EPI_ADDR) o[r] = v[r] + w[r];
@@ -227,6 +231,7 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
                     else *(u32x4*)(Cp + g) = *(const u32x4 VK_LDS*)(uintptr_t)(lds_region + a);      // (write-through for EVERY output measured neutral: profiles/r04_experiments.md)
                     // gelu'(u) is read again only by the backward pass: stored non-temporally so that it does not push the activation beside
                     // it -- the next GEMM's A operand -- out of the Infinity Cache
+                    if (VK_EPI_ABLATE & 1) continue;
                     if (EPI == VK_EPI_GELU) __builtin_nontemporal_store(*(const u32x4 VK_LDS*)(uintptr_t)(img2 + a), (u32x4*)(C2p + g));
                 }
             }
