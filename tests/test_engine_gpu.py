@@ -294,3 +294,47 @@ def test_attention_maps_against_oracle(name, train):
     assert out2[4] == ([None] * n_attn, [None] * n_attn)
     out3 = model2.bert(cb["input_ids"], cb["image_feat"], cb["image_loc"], cb["segment_ids"], cb["input_mask"], cb["image_mask"])
     assert out3[4] == ([], [])
+
+
+@pytest.mark.parametrize("switches", [{"VK_CHAIN": "all"}, {"VK_SOFT": "1"}])
+def test_handoff_switches_leave_the_step_unchanged(monkeypatch, switches):
+    """At the benchmark's shapes (batch 256: the only ones large enough for them) the FFN pairs as chain launches (VK_CHAIN=all: forward and
+    backward pair) or behind soft boundaries (VK_SOFT=1) give the losses and gradients of the default two fenced launches bit for bit --
+    the hand-off changes when a row block is read, never what is read -- and no waiting tile gives up."""
+    from oracle import volta_ref as R
+    from volta_amd import _lib as L
+    model, rcfg, sd = build("vilbert")
+    batch = R.synthetic_batch(rcfg, 256, 20, 36, seed=3)
+    cb = {k: v.cuda() for k, v in batch.items()}
+    args = (cb["input_ids"], cb["image_feat"], cb["image_loc"], cb["segment_ids"], cb["input_mask"], cb["image_mask"],
+            cb["lm_label_ids"], cb["image_label"], cb["image_cls"], None, None, None, None, None, cb["is_match"])
+    model.train()
+
+    def step():
+        for p in model.parameters():
+            p.grad = None
+        model.set_dropout_seed(9)
+        losses = model(*args)
+        sum(losses).sum().backward()
+        torch.cuda.synchronize()
+        return [float(l) for l in losses], {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    for k in ("VK_CHAIN", "VK_SOFT"):
+        monkeypatch.delenv(k, raising=False)
+    base_losses, base = step()
+    assert not any(op[0] == L.OP_GEMM_CHAIN for op in model._last[0].fwd.ops), "the default plan has no chain launch"
+    for k, v in switches.items():
+        monkeypatch.setenv(k, v)
+    model.__dict__["_engines"] = {}                    # the plan is compiled under the switches
+    for rep in range(3):
+        losses, grads = step()
+        eng = model._last[0]
+        if "VK_CHAIN" in switches:
+            assert any(op[0] == L.OP_GEMM_CHAIN for op in eng.fwd.ops) and any(op[0] == L.OP_GEMM_CHAIN for op in eng.bwd.ops)
+        assert eng.soft_error() == 0, "a waiting tile gave up"
+        assert np.allclose(losses, base_losses, rtol=1e-5), (losses, base_losses)      # the loss sums are accumulated with atomics
+        for k, g in grads.items():
+            if "embeddings.word_embeddings" in k or "token_type_embeddings" in k or "position_embeddings" in k:
+                assert torch.allclose(g, base[k], rtol=1e-4, atol=1e-7), k          # accumulated with atomics
+            else:
+                assert torch.equal(g, base[k]), k

@@ -110,14 +110,15 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint3
 // far below the bf16 output rounding); exp(-x^2/2) is shared between erf and the Gaussian density of the
 // derivative, so value + derivative cost one exp, one rcp and ~12 FMAs instead of two libm erff calls.
 __device__ __forceinline__ void gelu_both(float x, float& y, float& dy) {
-    const float ax = fabsf(x);
-    const float e = __expf(-0.5f * x * x);
-    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * 0.70710678118654752f * ax);   // bare v_rcp_f32 (1 ulp): __frcp_rn expands to the 10-instruction IEEE division
-    const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
-    const float erf_abs = 1.0f - poly * e;                       // erf(|x| / sqrt 2)
-    const float cdf = 0.5f * (1.0f + copysignf(erf_abs, x));
+    // constants folded by hand (the compiler may not reassociate): exp(-x^2 / 2) = exp2(x^2 * (-log2(e) / 2)) -- v_exp_f32 IS exp2 --, and the
+    // polynomial carries the 1/2 of cdf = 1/2 + 1/2 erf: 3 multiplies and 2 adds fewer per element of a VALU-bound epilogue (r04_experiments.md 8)
+    const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170f);
+    const float t = __builtin_amdgcn_rcpf(__builtin_fmaf(fabsf(x), 0.3275911f * 0.70710678118654752f, 1.0f));   // bare v_rcp_f32 (1 ulp): __frcp_rn expands to the 10-instruction IEEE division
+    const float poly = ((((0.5f * 1.061405429f * t - 0.5f * 1.453152027f) * t + 0.5f * 1.421413741f) * t - 0.5f * 0.284496736f) * t + 0.5f * 0.254829592f) * t;
+    const float half_erf = __builtin_fmaf(-poly, e, 0.5f);       // erf(|x| / sqrt 2) / 2
+    const float cdf = 0.5f + copysignf(half_erf, x);
     y = x * cdf;
-    dy = cdf + x * 0.39894228040143268f * e;
+    dy = __builtin_fmaf(x * 0.39894228040143268f, e, cdf);
 }
 __device__ __forceinline__ float gelu_f(float x) { float y, d; gelu_both(x, y, d); return y; }
 __device__ __forceinline__ float gelu_grad_f(float x) { float y, d; gelu_both(x, y, d); return d; }

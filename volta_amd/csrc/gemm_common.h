@@ -99,6 +99,9 @@ __device__ __forceinline__ void soft_wait(const int32_t* dep, int rb, int need, 
         }
     }
     __syncthreads();
+    // agent-scope acquire as the compiler's memory model spells it for this part (poll, then invalidate): no later load of this wave may be
+    // served from a line that a cache of this XCD fetched before the producer's write-through stores landed
+    asm volatile("buffer_inv sc1" ::: "memory");
 }
 __device__ __forceinline__ void soft_signal(int32_t* sig, int rb) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // every storing wave, before the barrier the adding lane passes
@@ -108,7 +111,7 @@ __device__ __forceinline__ void soft_signal(int32_t* sig, int rb) {
 
 __device__ __forceinline__ int even_up(int K, int ld) { const int e = (K + 1) & ~1; return e < ld ? e : ld; }
 
-#ifndef VK_EPI_ABLATE      // A/B builds (tools/runs): 1 = GELU epilogue without the gelu' stores, 2 = with trivial arithmetic, 3 = both
+#ifndef VK_EPI_ABLATE      // A/B builds (tools/runs): 1 = GELU epilogue without the gelu' stores, 2 = with trivial arithmetic, 3 = both; 4 = x R / + R epilogues without the loads of R
 #define VK_EPI_ABLATE 0
 #endif
 template <bool AT, int EPI, int TI, int TJ, int REGION = 16384>       // REGION: bytes of the wave-private LDS staging region
@@ -166,7 +169,7 @@ __device__ __forceinline__ void gemm_epilogue(const KProb& P, f32x4 (&acc)[TI][T
                 for (int ii = 0; ii < RB; ++ii) {
                     const char* rrow = Rp + ((size_t)(m_base + (i + ii) * 16 + lr) * ldr + (size_t)(n_base + gq * 4)) * 2;
 #pragma unroll
-                    for (int j = 0; j < TJ; ++j) rall[ii][j] = *(const u32x2*)(rrow + j * 32);
+                    for (int j = 0; j < TJ; ++j) rall[ii][j] = (VK_EPI_ABLATE & 4) ? u32x2{0x3F803F80u, 0x3F803F80u} : *(const u32x2*)(rrow + j * 32);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);

@@ -251,12 +251,13 @@ class StepEngine:
         # (profiles/r04_experiments.md: on gfx950 a barrier-less dispatch starts on an XCD only when that XCD's workgroups of the launch in
         # front are done, so there is no tail overlap to win, and the write-through hand-off costs what the shorter boundary saves)
         self.soft = os.environ.get("VK_SOFT", "0") == "1"
-        # FFN-up -> FFN-down as ONE persistent launch with row-block hand-off (vk_gemm_chain): "fwd" (default) the forward pair -- measured
-        # -0.08 ms per step (16.56 -> 16.48; per pair 205 -> 198 us from cold caches: the launch boundary goes, but the workgroups with three
-        # producer tiles set the pace, so the early finishers' head start does not shorten the launch); "all" also the backward pair
-        # (FFN-down dgrad x gelu' -> FFN-up dgrad): +0.12 ms, the weight gradients that need the first dgrad's output start a launch later;
-        # "0" two launches.  profiles/r04_experiments.md, profiles/r04_chain_stamps.txt
-        self.chain = os.environ.get("VK_CHAIN", "fwd")
+        # FFN-up -> FFN-down as ONE persistent launch with row-block hand-off (vk_gemm_chain): "0" (default) two launches; "fwd" the forward
+        # pair; "all" also the backward pair (FFN-down dgrad x gelu' -> FFN-up dgrad).  Measured (profiles/r04_experiments.md 2 and 9,
+        # r04_chain_stamps.txt): the launch boundary goes, but the workgroups with three producer tiles set the pace -- -0.08 ms per step for
+        # "fwd" while the consumer's poll was a bare counter read; with the acquire the memory model asks for behind the poll (buffer_inv:
+        # every waiting tile drops its XCD's cached operand lines) "fwd" costs +0.15 ms, "all" more.  Off: the default step has no
+        # intra-launch hand-off in it.
+        self.chain = os.environ.get("VK_CHAIN", "0")
         self.side_delay_us = int(os.environ.get("VK_SIDE_DELAY_US", "0"))
         # How a sub-layer's weight-gradient block (side stream) is started: "event" (default) -- the fork event of rounds 1-3; "gate" -- a
         # one-wave gate at the head of the block that the sub-layer's last dgrad releases as its first workgroup retires, no stream event
