@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--serial", action="store_true", help="run the side-stream blocks (weight gradients) inline: per-kernel profiles without concurrency")
     ap.add_argument("--no-dropout", action="store_true", help="DIAGNOSTIC, not the BASELINE workload (the line says so): every dropout probability 0 -- what the counter-based mask generation costs the step")
+    ap.add_argument("--no-optimizer", action="store_true", help="DIAGNOSTIC, not the BASELINE workload (the line says so): forward + backward only -- what clip + AdamW add to the step beyond what the next forward hides")
     ap.add_argument("--dump-ops", default=None, help="write the per-op timing table of the profiled steps to this file")
     return ap.parse_args()
 
@@ -195,8 +196,9 @@ def result_line(a, world, elapsed, t_issue, extra):
     out = {"metric": "image-text pairs/sec, %s pretrain step" % a.config, "value": pairs_s, "unit": "image-text pairs/s",
            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": a.dtype, "data": "synthetic",
-           "config": {"workload": "%s pretrain step (fwd+bwd+clip+AdamW%s), per-GPU batch %d, T=%d, %d regions (+1 global), objective 1, dropout %s"
-                      % (a.config, "+allreduce" if world > 1 else "", a.batch, a.seq_len, a.regions, "OFF (diagnostic run, not the BASELINE workload)" if a.no_dropout else "on"),
+           "config": {"workload": "%s pretrain step (%s%s), per-GPU batch %d, T=%d, %d regions (+1 global), objective 1, dropout %s"
+                      % (a.config, "fwd+bwd ONLY: diagnostic run, not the BASELINE workload" if a.no_optimizer else "fwd+bwd+clip+AdamW", "+allreduce" if world > 1 else "",
+                         a.batch, a.seq_len, a.regions, "OFF (diagnostic run, not the BASELINE workload)" if a.no_dropout else "on"),
                       "global_batch": a.batch * world, "seq_len": a.seq_len, "regions": a.regions, "parallelism": "dp%d" % world},
            "host_issue_ms_per_step": t_issue * 1e3 / a.steps}
     out.update(extra)
@@ -294,9 +296,10 @@ def main():
         lm, img, nsp = net(*args)
         loss = lm + img + nsp
         loss.backward()
-        clip_grad_norm_(model.parameters(), 5.0)
-        opt.step()
-        sched.step()
+        if not a.no_optimizer:
+            clip_grad_norm_(model.parameters(), 5.0)
+            opt.step()
+            sched.step()
         opt.zero_grad()
         return lm, img, nsp
 

@@ -568,6 +568,18 @@ static constexpr unsigned long long* g_stamps = nullptr;
 // CUs the persistent launches leave unclaimed (vk_gemm_reserve_cus): room for a collective's channel kernels beside the backward pass
 static std::atomic<int> g_reserved_cus{0};
 
+// Workgroups of a persistent launch: as few as walk the tile list in the same number of rounds, in whole multiples of 8 (a workgroup stays on its
+// XCD's chunk).  684 tiles on 256 CUs are 2.67 rounds = three tile times with 84 CUs idle in the last one; 232 workgroups x 3 tiles take the same three
+// tile times, finish together, and leave 24 CUs to whatever else is running for the WHOLE launch (the weight-gradient stream, LayerNorm rows, the
+// optimizer under the next forward).  Measured: forward + backward 15.74 -> 15.56 ms (profiles/r04_experiments.md 10).
+static int persistent_grid(int total) {
+    const int ncu = NUM_CU - g_reserved_cus.load(std::memory_order_relaxed);
+    if (total <= ncu) return total;
+    const int rounds = (total + ncu - 1) / ncu;
+    const int even = ((total + rounds - 1) / rounds + 7) & ~7;
+    return even < ncu ? even : ncu;
+}
+
 template <bool AT, bool BT, int KSPLIT>      // 4 / 3 / 2: K-split kernel with 256 / 192 / 128 columns; 0: 4-phase 256 x 256 (study builds)
 static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s, bool persistent, bool soft) {
     // soft: VK_GEMM_SOFT_START -- the dispatch packet goes out without the barrier bit (hipExtAnyOrderLaunch): workgroups start as CUs come
@@ -585,8 +597,7 @@ static int launch_layout(int epi, const KGroup& g, int total, hipStream_t s, boo
             if (persistent) {                                                                             \
                 auto kp = gemm256p_kernel<AT, BT, E, KSPLIT>;                                             \
                 static const hipError_t attr_p = hipFuncSetAttribute((const void*)kp, hipFuncAttributeMaxDynamicSharedMemorySize, LDS); (void)attr_p; \
-                const int ncu = NUM_CU - g_reserved_cus.load(std::memory_order_relaxed);                  \
-                hipExtLaunchKernelGGL(kp, dim3(total < ncu ? total : ncu), dim3(512), LDS, s, nullptr, nullptr, flags, g, total, g_stamps); \
+                hipExtLaunchKernelGGL(kp, dim3(persistent_grid(total)), dim3(512), LDS, s, nullptr, nullptr, flags, g, total, g_stamps); \
                 break;                                                                                    \
             }                                                                                             \
         }                                                                                                 \

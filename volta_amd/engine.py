@@ -259,6 +259,8 @@ class StepEngine:
         # intra-launch hand-off in it.
         self.chain = os.environ.get("VK_CHAIN", "0")
         self.side_delay_us = int(os.environ.get("VK_SIDE_DELAY_US", "0"))
+        if os.environ.get("VK_RESERVE_CUS"):                  # study knob: the persistent GEMM launches leave this many CUs unclaimed (process-wide)
+            L.lib.vk_gemm_reserve_cus(int(os.environ["VK_RESERVE_CUS"]))
         # How a sub-layer's weight-gradient block (side stream) is started: "event" (default) -- the fork event of rounds 1-3; "gate" -- a
         # one-wave gate at the head of the block that the sub-layer's last dgrad releases as its first workgroup retires, no stream event
         # (vk_gemm_problem::retire_flag + vk_gate_wait).  Built to take the cross-queue wake-up latency out of the schedule; measured
