@@ -459,6 +459,9 @@ typedef struct vk_adamw_args {
     float lr, beta1, beta2, eps, step_mult, grad_scale;
 } vk_adamw_args;
 int vk_adamw_step(const vk_adamw_args* a, vk_stream_t s);
+/* The same update (same bits) by `ncus` resident workgroups, each keeping one compute unit to itself and striding over the arena: the form
+ * for a step that runs on a stream of its own under the next forward pass, beside GEMM launches that claim the rest of the chip. */
+int vk_adamw_step_on(const vk_adamw_args* a, int ncus, vk_stream_t s);
 int vk_axpy_f32(float* y, const float* x, float alpha, int64_t n, vk_stream_t s);
 /* dst[i] = sum_{s < nslabs} src[s * slab_stride + i], i < n (fp32).  Combines the partial weight gradients of a
  * split-K wgrad: each K-chunk is an ordinary problem of the grouped TN launch writing its own slab. */

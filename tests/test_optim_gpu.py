@@ -186,3 +186,42 @@ def test_pipelined_adamw_under_the_next_forward_changes_nothing():
     assert float((p0 - p1).abs().max()) <= 1e-5 and float((m0 - m1).abs().max()) <= 1e-5
     assert float((s0.float() - s1.float()).abs().max()) <= 1e-2
     assert l0[0] != l0[-1]                                             # the model did move
+
+
+@pytest.mark.parametrize("ncus", [1, 24, 256])
+def test_adamw_step_on_gives_the_bits_of_adamw_step(ncus):
+    """vk_adamw_step_on (a few resident workgroups striding over the arena: the form the pipelined step runs under the next forward) leaves
+    exactly the parameters, moments and bf16 copies of vk_adamw_step -- chunk classes, skipped chunks, a clip coefficient and an arena that is
+    not a multiple of the kernel's 4-chunk blocks included."""
+    import ctypes as C
+    from volta_amd import _lib as L
+    nch = 4 * 24 * 4 * 3 + 7                         # three full trips of 24 workgroups and a ragged tail
+    n = nch * 1024
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    g = torch.randn(n, device="cuda", generator=gen) * 0.1
+    p0 = torch.randn(n, device="cuda", generator=gen)
+    m0 = torch.randn(n, device="cuda", generator=gen) * 0.01
+    v0 = torch.rand(n, device="cuda", generator=gen) * 1e-3
+    cls = torch.randint(0, 3, (nch,), device="cuda", generator=gen).to(torch.uint8)
+    cls[torch.rand(nch, device="cuda", generator=gen) < 0.1] = 255          # VK_CHUNK_SKIP
+    clip = torch.tensor([7.0, 0.71], device="cuda")
+    outs = []
+    for which in ("wide", "narrow"):
+        p, m, v = p0.clone(), m0.clone(), v0.clone()
+        sh = torch.zeros(n, device="cuda", dtype=torch.bfloat16)
+        a = L.AdamwArgs()
+        a.p, a.g, a.m, a.v, a.shadow, a.chunk_class, a.clip, a.n = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), sh.data_ptr(), cls.data_ptr(), clip.data_ptr(), n
+        for i, (lr, wd) in enumerate([(1.0, 0.01), (0.5, 0.0), (2.0, 0.1)]):
+            a.cls_lr_mult[i], a.cls_wd[i] = lr, wd
+        a.lr, a.beta1, a.beta2, a.eps, a.step_mult, a.grad_scale = 1e-3, 0.9, 0.999, 1e-6, 1.7, 0.5
+        for _ in range(2):
+            if which == "wide":
+                L.check(L.lib.vk_adamw_step(C.byref(a), L.stream_ptr()))
+            else:
+                L.check(L.lib.vk_adamw_step_on(C.byref(a), ncus, L.stream_ptr()))
+        torch.cuda.synchronize()
+        outs.append((p, m, v, sh))
+    for x, y in zip(*outs):
+        assert torch.equal(x, y)
+    skipped = (cls == 255).repeat_interleave(1024)
+    assert torch.equal(outs[1][0][skipped], p0[skipped]) and not torch.equal(outs[1][0][~skipped], p0[~skipped])

@@ -239,6 +239,7 @@ _sig("vk_mul_bf16", C.c_int, c_p, c_p, c_p, C.c_int64, c_p, C.c_int, c_p)
 _sig("vk_grad_norm_workspace_floats", C.c_int)
 _sig("vk_grad_norm_clip", C.c_int, c_p, C.c_int64, C.c_float, C.c_float, c_p, c_p, c_p)
 _sig("vk_adamw_step", C.c_int, C.POINTER(AdamwArgs), c_p)
+_sig("vk_adamw_step_on", C.c_int, C.POINTER(AdamwArgs), C.c_int, c_p)
 _sig("vk_grad_norm_clip_masked", C.c_int, c_p, C.c_int64, c_p, C.c_float, C.c_float, c_p, c_p, c_p)
 _sig("vk_grad_sqnorm_chunks", C.c_int, c_p, C.c_int64, C.c_int64, c_p, c_p, c_p)
 _sig("vk_grad_norm_from_chunks", C.c_int, c_p, C.c_int64, C.c_float, C.c_float, c_p, c_p)
@@ -272,7 +273,7 @@ EXPORTS = ["vk_version", "vk_device_arch", "vk_last_error", "vk_set_seed", "vk_c
            "vk_relu_bwd_bf16", "vk_copy_async", "vk_select_rows", "vk_gather_rows", "vk_scatter_rows_add", "vk_xent_fwd",
            "vk_xent_bwd", "vk_kl_fwd", "vk_kl_bwd", "vk_loss_finalize", "vk_pool_mul_fwd", "vk_pool_mul_bwd",
            "vk_pool_fuse_fwd", "vk_pool_fuse_bwd", "vk_text_end_rows", "vk_vlbert_obj_ids", "vk_vlbert_positions", "vk_vis_loss_fwd", "vk_vis_loss_bwd", "vk_nce_negatives",
-           "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_grad_norm_clip_masked", "vk_grad_sqnorm_chunks", "vk_grad_norm_from_chunks", "vk_adamw_step",
+           "vk_mask_prep", "vk_mul_bf16", "vk_grad_norm_workspace_floats", "vk_grad_norm_clip", "vk_grad_norm_clip_masked", "vk_grad_sqnorm_chunks", "vk_grad_norm_from_chunks", "vk_adamw_step", "vk_adamw_step_on",
            "vk_axpy_f32", "vk_sum_slabs_f32", "vk_sum_slabs_bf16", "vk_memset_async", "vk_hold_cus", "vk_gate_wait", "vk_bump_u64", "vk_store_u64", "vk_gate_value", "vk_comm_standin", "vk_gemm_reserve_cus", "vk_side_tail", "vk_run_ops", "vk_run_ops_timed", "vk_side_join", "vk_side_join_from", "vk_side_stream", "vk_side_enable", "vk_concap_batch",
            "vk_lmdb_open", "vk_lmdb_close", "vk_lmdb_entries", "vk_lmdb_first", "vk_lmdb_next", "vk_lmdb_get", "vk_concap_record_decode", "vk_concap_records_decode", "vk_b64_decode",
            "vk_wordpiece_open", "vk_wordpiece_close", "vk_wordpiece_vocab_size", "vk_wordpiece_token_id", "vk_wordpiece_encode", "vk_wordpiece_encode_batch"]

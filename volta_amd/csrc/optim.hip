@@ -86,6 +86,17 @@ __global__ __launch_bounds__(64) void sqnorm_from_groups_kernel(const double* gr
     }
 }
 
+// One element of the update, spelled with explicit fused multiply-adds and no further contraction: vk_adamw_step and vk_adamw_step_on give
+// the same bits whatever the compiler makes of the code around it.
+__device__ __forceinline__ void adamw_element(float& p, float& m, float& v, float g, float gs, float b1, float b2, float eps, float step, float lr_wd) {
+#pragma clang fp contract(off)
+    const float gr = g * gs;
+    m = __builtin_fmaf(b1, m, (1.f - b1) * gr);
+    v = __builtin_fmaf(b2, v, ((1.f - b2) * gr) * gr);
+    p = __builtin_fmaf(-step, m / (sqrtf(v) + eps), p);
+    if (lr_wd > 0.f) p = __builtin_fmaf(-lr_wd, p, p);
+}
+
 __global__ __launch_bounds__(256) void adamw_kernel(vk_adamw_args a) {
     const size_t chunk = blockIdx.x;
     const int cls = a.chunk_class ? a.chunk_class[chunk] : 0;
@@ -100,14 +111,62 @@ __global__ __launch_bounds__(256) void adamw_kernel(vk_adamw_args a) {
     const float step = lr * a.step_mult;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-        const float gr = g[r] * gs;
-        m[r] = a.beta1 * m[r] + (1.f - a.beta1) * gr;
-        v[r] = a.beta2 * v[r] + (1.f - a.beta2) * gr * gr;
-        p[r] = p[r] - step * (m[r] / (sqrtf(v[r]) + a.eps));
-        if (wd > 0.f) p[r] = p[r] - lr * wd * p[r];
+        float pr = p[r], mr = m[r], vr = v[r];
+        adamw_element(pr, mr, vr, g[r], gs, a.beta1, a.beta2, a.eps, step, lr * wd);
+        p[r] = pr; m[r] = mr; v[r] = vr;
     }
     __builtin_nontemporal_store(p, (f32x4*)(a.p + i)); __builtin_nontemporal_store(m, (f32x4*)(a.m + i)); __builtin_nontemporal_store(v, (f32x4*)(a.v + i));
     if (a.shadow) *(u32x2*)((uint16_t*)a.shadow + i) = u32x2{pack2bf(p[0], p[1]), pack2bf(p[2], p[3])};
+}
+
+// The same update by a few RESIDENT workgroups (vk_adamw_step_on): 512 threads, an LDS footprint that keeps the compute unit to itself, eight
+// 2048-element blocks in flight per trip (256 KiB of loads per CU -- what one CU needs to stream at ~100 GB/s against HBM latency).  For the
+// optimizer step that runs under the next forward pass: the persistent GEMM launches there claim 232 of the 256 CUs (gemm256.hip,
+// persistent_grid) and a full-width AdamW launch only gets CUs when a GEMM launch gives them up -- it delays the forward by what it takes
+// (measured: pipelined or not, clip + AdamW add 1.25 ms to the step).  24 workgroups on the CUs the GEMMs leave alone do not.
+__global__ __launch_bounds__(512) void adamw_narrow_kernel(vk_adamw_args a) {
+    constexpr int U = 8;                                      // 2048-element blocks in flight per workgroup: 512 threads x 8 x 4 arrays x 16 bytes = 256 KiB of loads
+    const size_t nch = (size_t)a.n / 1024;
+    const int sub = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)), t4 = (threadIdx.x & 255) * 4;
+    const float gs = a.grad_scale * (a.clip ? a.clip[1] : 1.f);
+    for (size_t blk = blockIdx.x; blk * 2 < nch; blk += (size_t)gridDim.x * U) {
+        f32x4 g[U], p[U], m[U], v[U];
+        int cls[U];
+        size_t at[U];
+        // every load of the trip goes out before anything is waited for: no branch in here (a chunk past the end re-reads the last one,
+        // a skipped chunk is read and dropped)
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t chunk = (blk + (size_t)u * gridDim.x) * 2 + sub;
+            const size_t c = chunk < nch ? chunk : nch - 1;
+            int k = 0;
+            if (a.chunk_class) {                              // wave-uniform (a wave lies inside one chunk): fetched on the scalar path, as the aligned word that holds the byte
+                const uintptr_t ca = (uintptr_t)(a.chunk_class + c);
+                k = (int)((*(const uint32_t*)(ca & ~(uintptr_t)3) >> (8 * (ca & 3))) & 255u);
+            }
+            cls[u] = chunk < nch ? k : VK_CHUNK_SKIP;
+            at[u] = c * 1024 + t4;
+            g[u] = __builtin_nontemporal_load((const f32x4*)(a.g + at[u]));
+            p[u] = __builtin_nontemporal_load((const f32x4*)(a.p + at[u]));
+            m[u] = __builtin_nontemporal_load((const f32x4*)(a.m + at[u]));
+            v[u] = __builtin_nontemporal_load((const f32x4*)(a.v + at[u]));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int c = __builtin_amdgcn_readfirstlane(cls[u]);
+            if (c == VK_CHUNK_SKIP) continue;
+            const float lr = a.lr * a.cls_lr_mult[c], wd = a.cls_wd[c], step = lr * a.step_mult;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float pr = p[u][r], mr = m[u][r], vr = v[u][r];
+                adamw_element(pr, mr, vr, g[u][r], gs, a.beta1, a.beta2, a.eps, step, lr * wd);
+                p[u][r] = pr; m[u][r] = mr; v[u][r] = vr;
+            }
+            const size_t i = at[u];
+            __builtin_nontemporal_store(p[u], (f32x4*)(a.p + i)); __builtin_nontemporal_store(m[u], (f32x4*)(a.m + i)); __builtin_nontemporal_store(v[u], (f32x4*)(a.v + i));
+            if (a.shadow) *(u32x2*)((uint16_t*)a.shadow + i) = u32x2{pack2bf(p[u][0], p[u][1]), pack2bf(p[u][2], p[u][3])};
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void axpy_kernel(float* y, const float* x, float alpha, size_t n4) {
@@ -290,6 +349,16 @@ extern "C" int vk_adamw_step(const vk_adamw_args* a, vk_stream_t s) {
     if (a->n == 0) return 0;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)(a->n / 1024)), dim3(256), 0, (hipStream_t)s, *a);
     return check_launch("vk_adamw_step");
+}
+
+extern "C" int vk_adamw_step_on(const vk_adamw_args* a, int ncus, vk_stream_t s) {
+    if (a->n % 1024) return set_error("vk_adamw_step_on: arena length must be a multiple of 1024 elements");
+    if (ncus < 1 || ncus > 256) return set_error("vk_adamw_step_on: %d compute units", ncus);
+    if (a->n == 0) return 0;
+    constexpr int FOOTPRINT = 96 * 1024;             // more than half a CU's LDS: one workgroup per compute unit
+    static const hipError_t attr = hipFuncSetAttribute((const void*)adamw_narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, FOOTPRINT); (void)attr;
+    hipLaunchKernelGGL(adamw_narrow_kernel, dim3((unsigned)ncus), dim3(512), FOOTPRINT, (hipStream_t)s, *a);
+    return check_launch("vk_adamw_step_on");
 }
 
 extern "C" int vk_axpy_f32(float* y, const float* x, float alpha, int64_t n, vk_stream_t s) {

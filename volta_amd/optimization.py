@@ -10,6 +10,7 @@ coefficient never leave the device.  The arithmetic (decay after the Adam update
 eps outside the bias correction) follows pytorch-transformers 1.1.0 and is pinned by the oracle tests."""
 import ctypes as C
 import math
+import os
 
 import torch
 import weakref
@@ -215,6 +216,14 @@ class AdamW(Optimizer):
                 f["stream"] = independent_stream(engine_streams(), device=arena.device, soft_avoid=[comm] if comm is not None else [])
             f["bounds"] = [nchunks * (i + 1) // n for i in range(n)]
             f["events"] = [torch.cuda.Event() for _ in range(n)]
+            # Switch, off by default: the ranges from index VK_OPT_NARROW_FROM on are stepped by VK_OPT_CUS RESIDENT workgroups, one per compute
+            # unit (vk_adamw_step_on), on the CUs the forward's persistent GEMM launches leave alone.  Built because clip + AdamW add 1.25 ms to
+            # the step whether pipelined or not (a full-width launch only gets CUs when a GEMM launch gives them up); measured
+            # (profiles/r04_experiments.md 10): one CU streams this update at 50 GB/s alone and 37 under the forward, so 24 of them need 7 ms
+            # for what the forward waits for after 5 -- 18.4 ms per step with every range but the first on 24 CUs, 16.95-17.05 with only the
+            # last two to five ranges, against 16.65-16.7 full-width.
+            f["narrow"] = int(os.environ.get("VK_OPT_CUS", "0"))
+            f["narrow_from"] = int(os.environ.get("VK_OPT_NARROW_FROM", "4"))
         side, bounds, events = f["stream"], f["bounds"], f["events"]
         side.wait_stream(torch.cuda.current_stream())          # gradients, their norm and the clip coefficient are final
         if clip is not None:
@@ -223,13 +232,16 @@ class AdamW(Optimizer):
         with torch.cuda.stream(side):
             sp = C.c_void_p(side.cuda_stream)
             lo = 0
-            for hi, ev in zip(bounds, events):
+            for idx, (hi, ev) in enumerate(zip(bounds, events)):
                 if hi > lo:
                     off = lo * 1024
                     a.p, a.g, a.m, a.v = base[0] + 4 * off, base[1] + 4 * off, base[2] + 4 * off, base[3] + 4 * off
                     a.shadow, a.chunk_class = base[4] + 2 * off, base[5] + lo
                     a.n = (hi - lo) * 1024
-                    L.check(L.lib.vk_adamw_step(C.byref(a), sp))
+                    if idx < f["narrow_from"] or f["narrow"] <= 0:
+                        L.check(L.lib.vk_adamw_step(C.byref(a), sp))
+                    else:
+                        L.check(L.lib.vk_adamw_step_on(C.byref(a), f["narrow"], sp))
                 ev.record(side)
                 lo = hi
         arena.opt_pending = (bounds, events)
