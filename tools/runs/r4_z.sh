@@ -1,9 +1,5 @@
 mkdir -p gpurun_out/r4z
-for i in 1 2; do
-for c in "0 9" "24 3" "24 4" "24 5" "24 6"; do
-set -- $c
-VK_OPT_CUS=$1 VK_OPT_NARROW_FROM=$2 timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-kernel-timing > gpurun_out/r4z/b.json 2> gpurun_out/r4z/b.err || exit 1
-python3 -c "
-import json; d=json.loads(open('gpurun_out/r4z/b.json').read().strip().splitlines()[-1]); print('[VK_OPT_CUS=$1 from range $2]', round(d['ms_per_step'],3))"
-done
-done
+timeout -k 10 1100 python3 -m pytest tests -m gpu -x -q > gpurun_out/r4z/tests_full.log 2>&1
+rc=$?; tail -4 gpurun_out/r4z/tests_full.log
+if [ $rc -ne 0 ]; then exit $rc; fi
+timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -3
