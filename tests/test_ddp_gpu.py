@@ -98,3 +98,49 @@ def test_gate_ordered_reduction_and_gate_started_weight_gradients_match_plain_ba
             model.__dict__["_ddp"] = None
     finally:
         dist.destroy_process_group()
+
+
+def test_zero1_in_the_reference_construction_order():
+    """mode="zero1" on the real engine with the reference's order of construction (model -> DistributedDataParallel -> optimizer -> first
+    backward, train_concap.py:227-253): the optimizer is known to the arena from its construction on, so the wrapper's guard -- it refuses
+    a backward whose sharded gradients no volta_amd optimizer would pick up -- lets the first backward through; without an optimizer it
+    raises.  Two clip + AdamW steps leave the master weights of the unsharded wrapper (one-rank group: the shard is the whole bucket)."""
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_engine_gpu import build
+    from oracle import volta_ref as R
+    from volta_amd.parallel import DistributedDataParallel
+    from volta_amd.optimization import AdamW, clip_grad_norm_
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29563")
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        finals = {}
+        for mode in ("allreduce", "zero1"):
+            model, rcfg, sd = build("vilbert")
+            batch = R.synthetic_batch(rcfg, 4, 20, 36, seed=7)
+            cb = {k: v.cuda() for k, v in batch.items()}
+            args = (cb["input_ids"], cb["image_feat"], cb["image_loc"], cb["segment_ids"], cb["input_mask"], cb["image_mask"],
+                    cb["lm_label_ids"], cb["image_label"], cb["image_cls"], None, None, None, None, None, cb["is_match"])
+            model.train()
+            model.set_dropout_seed(5)
+            ddp = DistributedDataParallel(model, message_size=2000000, mode=mode)
+            if mode == "zero1":
+                with pytest.raises(RuntimeError, match="zero1"):
+                    sum(ddp(*args)).sum().backward()              # nobody would step these shards
+                model.set_dropout_seed(5)
+            opt = AdamW(model.parameters(), lr=1e-3, weight_decay=0.01)
+            for step in range(2):
+                sum(ddp(*args)).sum().backward()                  # the FIRST backward comes before any optimizer.step()
+                clip_grad_norm_(model.parameters(), 0.5)
+                opt.step()
+                opt.zero_grad()
+            torch.cuda.synchronize()
+            if mode == "zero1":
+                assert ddp.reducer.sharded, "no bucket was sharded"
+            finals[mode] = model._arena.master.clone()
+            model.__dict__["_ddp"] = None
+        err = float((finals["allreduce"] - finals["zero1"]).norm() / finals["allreduce"].norm())
+        assert err <= 1e-6, err
+    finally:
+        dist.destroy_process_group()

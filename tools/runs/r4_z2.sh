@@ -1,3 +1,3 @@
 mkdir -p gpurun_out/r4z
-timeout -k 10 300 python3 tools/bench_adamw.py > gpurun_out/r4z/adamw.txt 2>&1
-cat gpurun_out/r4z/adamw.txt
+timeout -k 10 600 python3 -m pytest tests/test_ddp_gpu.py tests/test_optim_gpu.py -x -q > gpurun_out/r4z/tests2.log 2>&1
+tail -12 gpurun_out/r4z/tests2.log | cut -c1-220

@@ -71,6 +71,14 @@ class AdamW(Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, correct_bias=correct_bias))
         self._fused = None
         self._overlap = (bool(overlap_with_forward), int(overlap_ranges))
+        # known to the model's arena from construction on (not only from the first step): DistributedDataParallel(mode="zero1") refuses to
+        # start a backward whose sharded gradients no volta_amd optimizer would pick up, and the reference's order is model -> DDP -> optimizer
+        # -> first backward (train_concap.py:227-253).  Parameters that are not (yet) a materialised volta_amd model's stay lazy (_setup).
+        try:
+            _, arena = _arena_of([p for g in self.param_groups for p in g["params"]])
+            arena._vk_adamw = weakref.ref(self)
+        except RuntimeError:
+            pass
 
     def _setup(self):
         allp = [p for g in self.param_groups for p in g["params"]]
